@@ -1,0 +1,153 @@
+/*
+ * pointops_amd.h -- C ABI of libpointops_amd.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the batched point-cloud neighbour hot path of
+ * pytorch3d_pointops.  Each entry point replaces one operator of the reference's
+ * pybind11 module `pytorch3d_pointops._C` (reference: csrc/ext.cpp:15-27); the
+ * argument meaning, padding conventions and output layout are the reference's.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed / torch CUDA-HIP tensor storage),
+ *     dense row-major, fp32 for point data and int64 for lengths / indices;
+ *   - inputs are borrowed and never written; outputs are FULLY written by the call
+ *     (padding included), so callers may pass uninitialised buffers;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls enqueue work and
+ *     return without synchronising (the reference does the same on its current
+ *     stream: csrc/knn/knn.cu:331);
+ *   - the calling thread's current HIP device must own the buffers;
+ *   - return value: 0 on success, a negative POINTOPS_E* code otherwise;
+ *     pointops_last_error() gives a thread-local message.
+ *   - no torch types, no C++ types, no global state besides the error string.
+ */
+#ifndef POINTOPS_AMD_H_
+#define POINTOPS_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POINTOPS_OK 0
+#define POINTOPS_EINVAL (-1)      /* bad argument (shape, norm, K ...)           */
+#define POINTOPS_ELAUNCH (-2)     /* HIP launch / runtime error                  */
+#define POINTOPS_EWORKSPACE (-3)  /* workspace too small                         */
+
+#define POINTOPS_ABI_VERSION 1
+
+/* Library identification: ABI version and the ISA the kernels were built for. */
+int pointops_abi_version(void);
+const char* pointops_target_arch(void); /* "gfx950" */
+const char* pointops_last_error(void);
+
+/*
+ * K nearest neighbours -- replaces `_C.knn_points_idx`
+ * (reference: csrc/knn/knn.h:59-80, CPU semantics csrc/knn/knn_cpu.cpp:13-69).
+ *   p1 (N,P1,D), p2 (N,P2,D), lengths1 (N,), lengths2 (N,), norm in {1,2}, K >= 1.
+ *   idxs (N,P1,K) int64 and dists (N,P1,K) fp32: for each query the K smallest
+ *   (dist, idx) pairs in ascending lexicographic order; rows >= lengths1[n] and
+ *   slots >= lengths2[n] are 0 / 0.0f.  Distances are unfused fp32
+ *   ((dx*dx + dy*dy) + dz*dz), i.e. bit-equal to the reference CPU path.
+ *   `version` is accepted for signature compatibility (reference: knn.h:45-57):
+ *   -1 = auto; 0..3 select a kernel family when valid, exactly like the reference
+ *   they never change results.
+ *   workspace: pointops_knn_workspace_bytes() bytes of device scratch (may be NULL
+ *   when that returns 0).
+ */
+size_t pointops_knn_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t D,
+                                    int64_t K, int version);
+int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* lengths1,
+                            const int64_t* lengths2, int64_t N, int64_t P1, int64_t P2,
+                            int64_t D, int norm, int64_t K, int version, int64_t* idxs,
+                            float* dists, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
+/* Replaces `_C.knn_check_version` (reference: csrc/knn/knn.h:161, knn.cu:292-303). */
+int pointops_knn_check_version(int version, int64_t D, int64_t K);
+
+/*
+ * KNN backward -- replaces `_C.knn_points_backward`
+ * (reference: csrc/knn/knn.h:127-149, csrc/knn/knn_cpu.cpp:75-128).
+ *   grad_p1 (N,P1,D) is a per-query sum over k in k order (deterministic, equal to
+ *   the CPU order); grad_p2 (N,P2,D) is a scatter-add (fp32 atomics, order-dependent
+ *   last bits, like the reference CUDA path csrc/knn/knn.cu:514-515,538).
+ *   Skips k >= min(lengths2[n], K), i >= lengths1[n] and idx == -1.
+ */
+int pointops_knn_points_backward(const float* p1, const float* p2, const int64_t* lengths1,
+                                 const int64_t* lengths2, const int64_t* idxs,
+                                 const float* grad_dists, int64_t N, int64_t P1, int64_t P2,
+                                 int64_t D, int64_t K, int norm, float* grad_p1,
+                                 float* grad_p2, void* stream);
+
+/*
+ * Ball query -- replaces `_C.ball_query`
+ * (reference: csrc/ball_query/ball_query.h:62-93, ball_query_cpu.cpp:12-54).
+ *   First K points of p2 (index order) with dist2 < radius*radius (fp32 product,
+ *   strict); idxs padded with -1, dists with 0.
+ */
+int pointops_ball_query(const float* p1, const float* p2, const int64_t* lengths1,
+                        const int64_t* lengths2, int64_t N, int64_t P1, int64_t P2, int64_t D,
+                        int64_t K, float radius, int64_t* idxs, float* dists, void* stream);
+
+/*
+ * Farthest point sampling -- replaces `_C.sample_farthest_points`
+ * (reference: csrc/sample_farthest_points/sample_farthest_points.h:55-76,
+ *  sample_farthest_points_cpu.cpp:14-103).
+ *   points (N,P,D), lengths (N,), K (N,), start_idxs (N,), out idxs (N,max_K) int64
+ *   padded with -1 beyond min(lengths[n], K[n]).  max_K = max(K) is passed by the
+ *   host (the reference reads it with a host sync: sample_farthest_points.cu:132).
+ *   min_dist_ws: device scratch of N*P floats (the running min-distance array).
+ */
+int pointops_sample_farthest_points(const float* points, const int64_t* lengths,
+                                    const int64_t* K, const int64_t* start_idxs, int64_t N,
+                                    int64_t P, int64_t D, int64_t max_K, int64_t* idxs,
+                                    float* min_dist_ws, void* stream);
+
+/*
+ * packed <-> padded -- replace `_C.packed_to_padded` / `_C.padded_to_packed`
+ * (reference: csrc/packed_to_padded_tensor/packed_to_padded_tensor.h:78-113,
+ *  packed_to_padded_tensor_cpu.cpp:11-70).
+ *   packed (F,D), first_idxs (B,), padded (B,max_size,D); cloud b owns packed rows
+ *   [first_idxs[b], first_idxs[b+1]) (last cloud: F).  Padding is zero-filled; packed
+ *   rows owned by no cloud are zero.
+ */
+int pointops_packed_to_padded(const float* packed, const int64_t* first_idxs, int64_t F,
+                              int64_t B, int64_t max_size, int64_t D, float* padded,
+                              void* stream);
+int pointops_padded_to_packed(const float* padded, const int64_t* first_idxs, int64_t F,
+                              int64_t B, int64_t max_size, int64_t D, float* packed,
+                              void* stream);
+
+/*
+ * Neighbour gather -- the device half of `knn_gather` / `masked_gather`
+ * (reference: functions/knn.py:200-250, functions/utils.py:20-65).
+ *   x (N,M,U), idx (N,L,K) -> out (N,L,K,U) with out[n,l,k,:] = x[n, idx[n,l,k], :];
+ *   zero where k >= lengths[n] (lengths may be NULL) or idx < 0.
+ * Backward: grad_x (N,M,U) += scatter of grad_out with the same masks (fp32 atomics);
+ *   grad_x is zero-filled by the call.
+ */
+int pointops_gather_neighbors(const float* x, const int64_t* idx, const int64_t* lengths,
+                              int64_t N, int64_t M, int64_t U, int64_t L, int64_t K,
+                              float* out, void* stream);
+int pointops_gather_neighbors_backward(const float* grad_out, const int64_t* idx,
+                                       const int64_t* lengths, int64_t N, int64_t M,
+                                       int64_t U, int64_t L, int64_t K, float* grad_x,
+                                       void* stream);
+
+/*
+ * Chamfer point-loss reduction -- the fused tail of
+ * `_chamfer_distance_single_direction` (reference: functions/chamfer.py:134-185)
+ * for point_reduction in {"sum","mean"}:
+ *   out[n] = (sum_{i < lengths[n]} dists[n,i]) * (weights ? weights[n] : 1)
+ *            / (mean ? max(lengths[n],1) : 1)
+ *   dists (N,P) are the K=1 KNN distances.  Summation order is a fixed tree per
+ *   cloud (deterministic), compared with the reference at 1e-5 relative.
+ */
+int pointops_chamfer_reduce(const float* dists, const int64_t* lengths, const float* weights,
+                            int64_t N, int64_t P, int mean, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POINTOPS_AMD_H_ */

@@ -1,0 +1,292 @@
+"""Operator boundary: the same callables as the reference's pybind11 module
+``pytorch3d_pointops._C`` (reference: csrc/ext.cpp:15-27), implemented as ctypes
+calls into ``lib/libpointops_amd.so`` (C ABI: include/pointops_amd.h).
+
+PyTorch is plumbing only here: it owns device memory (outputs are fresh tensors on
+the input device, like the reference's ``at::zeros`` / ``at::full``), the current
+HIP stream and the device guard.  There is NO CPU implementation behind these
+functions: CPU tensors raise ``RuntimeError`` (the mirror image of the reference's
+"Not compiled with GPU support." -- csrc/knn/knn.h:74), and a missing shared
+library raises at import of this module.
+"""
+import ctypes
+import os
+
+import torch  # must be imported first: loads the process-wide HIP runtime (libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpointops_amd.so")
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/pointops_amd.h
+_SIGNATURES = {
+    "pointops_abi_version": (_int, []),
+    "pointops_target_arch": (ctypes.c_char_p, []),
+    "pointops_last_error": (ctypes.c_char_p, []),
+    "pointops_knn_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _int]),
+    "pointops_knn_points_idx": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _i64, _int,
+                                       _vp, _vp, _vp, _sz, _vp]),
+    "pointops_knn_check_version": (_int, [_int, _i64, _i64]),
+    "pointops_knn_points_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
+                                            _i64, _int, _vp, _vp, _vp]),
+    "pointops_ball_query": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _vp, _vp,
+                                   _vp]),
+    "pointops_sample_farthest_points": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp,
+                                               _vp]),
+    "pointops_packed_to_padded": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "pointops_padded_to_packed": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "pointops_gather_neighbors": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "pointops_gather_neighbors_backward": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp,
+                                                  _vp]),
+    "pointops_chamfer_reduce": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m pytorch3d_pointops_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pointops_abi_version() != 1:
+        raise ImportError("libpointops_amd.so ABI version mismatch")
+    return lib
+
+
+_lib = _load()
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def _check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed ({code}): {_lib.pointops_last_error().decode()}")
+
+
+def _require_gpu(*tensors):
+    dev = None
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                "pytorch3d_pointops_amd is a GPU-only (MI355X / gfx950) implementation: got a CPU "
+                "tensor and there is no CPU fallback."
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("All tensors must be on the same GPU device")
+    return dev
+
+
+def _contig(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---------------------------------------------------------------------------
+# reference: csrc/knn/knn.h:59-80 -- returns (idx, dists), NOT (dists, idx)
+# ---------------------------------------------------------------------------
+def knn_points_idx(p1, p2, lengths1, lengths2, norm: int, K: int, version: int = -1):
+    dev = _require_gpu(p1, p2, lengths1, lengths2)
+    if p1.dtype != torch.float32 or p2.dtype != torch.float32:
+        raise RuntimeError("expected scalar type Float for p1/p2")  # CPU ref: same restriction
+    if lengths1.dtype != torch.int64 or lengths2.dtype != torch.int64:
+        raise RuntimeError("lengths1/lengths2 must be int64")
+    p1, p2 = p1.contiguous(), p2.contiguous()  # reference CUDA path: knn.cu:373-376
+    lengths1, lengths2 = lengths1.contiguous(), lengths2.contiguous()
+    N, P1, D = p1.shape
+    P2 = p2.shape[1]
+    if p2.shape[0] != N or p2.shape[2] != D or lengths1.shape != (N,) or lengths2.shape != (N,):
+        raise RuntimeError("knn_points_idx: inconsistent shapes")
+    with torch.cuda.device(dev):
+        idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
+        dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
+        ws_bytes = _lib.pointops_knn_workspace_bytes(N, P1, P2, D, K, version)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+        _check(
+            _lib.pointops_knn_points_idx(p1.data_ptr(), p2.data_ptr(), lengths1.data_ptr(),
+                                         lengths2.data_ptr(), N, P1, P2, D, int(norm), int(K),
+                                         int(version), idxs.data_ptr(), dists.data_ptr(),
+                                         ws.data_ptr() if ws is not None else None, ws_bytes,
+                                         _stream()),
+            "knn_points_idx",
+        )
+    return idxs, dists
+
+
+def knn_check_version(version: int, D: int, K: int) -> bool:
+    """reference: csrc/knn/knn.h:161 (GPU builds only)."""
+    return bool(_lib.pointops_knn_check_version(int(version), int(D), int(K)))
+
+
+# reference: csrc/knn/knn.h:127-149
+def knn_points_backward(p1, p2, lengths1, lengths2, idxs, norm: int, grad_dists):
+    dev = _require_gpu(p1, p2, lengths1, lengths2, idxs, grad_dists)
+    if p1.dtype != torch.float32 or p2.dtype != torch.float32 or grad_dists.dtype != torch.float32:
+        raise RuntimeError("expected scalar type Float")
+    p1, p2 = p1.contiguous(), p2.contiguous()
+    lengths1, lengths2 = lengths1.contiguous(), lengths2.contiguous()
+    idxs, grad_dists = idxs.contiguous(), grad_dists.contiguous()
+    N, P1, D = p1.shape
+    P2 = p2.shape[1]
+    K = idxs.shape[2]
+    if idxs.shape != (N, P1, K) or grad_dists.shape != (N, P1, K):
+        raise RuntimeError("knn_points_backward: inconsistent shapes")
+    with torch.cuda.device(dev):
+        grad_p1 = torch.empty((N, P1, D), dtype=torch.float32, device=dev)
+        grad_p2 = torch.empty((N, P2, D), dtype=torch.float32, device=dev)
+        _check(
+            _lib.pointops_knn_points_backward(p1.data_ptr(), p2.data_ptr(), lengths1.data_ptr(),
+                                              lengths2.data_ptr(), idxs.data_ptr(),
+                                              grad_dists.data_ptr(), N, P1, P2, D, K, int(norm),
+                                              grad_p1.data_ptr(), grad_p2.data_ptr(), _stream()),
+            "knn_points_backward",
+        )
+    return grad_p1, grad_p2
+
+
+# reference: csrc/ball_query/ball_query.h:62-93 -- returns (idx, dists)
+def ball_query(p1, p2, lengths1, lengths2, K: int, radius: float):
+    dev = _require_gpu(p1, p2, lengths1, lengths2)
+    if p1.dtype != torch.float32 or p2.dtype != torch.float32:
+        raise RuntimeError("expected scalar type Float for p1/p2")
+    p1, p2 = p1.contiguous(), p2.contiguous()  # ball_query.h:74-77
+    lengths1, lengths2 = lengths1.contiguous(), lengths2.contiguous()
+    N, P1, D = p1.shape
+    P2 = p2.shape[1]
+    with torch.cuda.device(dev):
+        idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
+        dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
+        _check(
+            _lib.pointops_ball_query(p1.data_ptr(), p2.data_ptr(), lengths1.data_ptr(),
+                                     lengths2.data_ptr(), N, P1, P2, D, int(K), float(radius),
+                                     idxs.data_ptr(), dists.data_ptr(), _stream()),
+            "ball_query",
+        )
+    return idxs, dists
+
+
+# reference: csrc/sample_farthest_points/sample_farthest_points.h:55-76
+def sample_farthest_points(points, lengths, K, start_idxs):
+    dev = _require_gpu(points, lengths, K, start_idxs)
+    if points.dtype != torch.float32:
+        raise RuntimeError("expected scalar type Float for points")
+    points = points.contiguous()
+    lengths, K, start_idxs = lengths.contiguous(), K.contiguous(), start_idxs.contiguous()
+    N, P, D = points.shape
+    if lengths.shape != (N,) or K.shape != (N,) or start_idxs.shape != (N,):
+        raise RuntimeError("sample_farthest_points: lengths, K and start_idxs must have shape (N,)")
+    # host sync, as in the reference (sample_farthest_points.cu:132)
+    max_K = int(K.max().item()) if N > 0 else 0
+    with torch.cuda.device(dev):
+        idxs = torch.empty((N, max_K), dtype=torch.int64, device=dev)
+        ws = torch.empty((N, P), dtype=torch.float32, device=dev)
+        _check(
+            _lib.pointops_sample_farthest_points(points.data_ptr(), lengths.data_ptr(), K.data_ptr(),
+                                                 start_idxs.data_ptr(), N, P, D, max_K,
+                                                 idxs.data_ptr(), ws.data_ptr(), _stream()),
+            "sample_farthest_points",
+        )
+    return idxs
+
+
+# reference: csrc/packed_to_padded_tensor/packed_to_padded_tensor.h:78-94
+def packed_to_padded(inputs_packed, first_idxs, max_size: int):
+    dev = _require_gpu(inputs_packed, first_idxs)
+    if inputs_packed.dim() != 2:
+        raise RuntimeError("inputs_packed must be a 2-dimensional tensor")
+    _contig(inputs_packed, "inputs_packed")
+    _contig(first_idxs, "first_idxs")
+    F, D = inputs_packed.shape
+    B = first_idxs.shape[0]
+    with torch.cuda.device(dev):
+        out = torch.empty((B, max_size, D), dtype=torch.float32, device=dev)
+        _check(
+            _lib.pointops_packed_to_padded(inputs_packed.data_ptr(), first_idxs.data_ptr(), F, B,
+                                           int(max_size), D, out.data_ptr(), _stream()),
+            "packed_to_padded",
+        )
+    return out
+
+
+# reference: csrc/packed_to_padded_tensor/packed_to_padded_tensor.h:97-113
+def padded_to_packed(inputs_padded, first_idxs, num_inputs: int):
+    dev = _require_gpu(inputs_padded, first_idxs)
+    if inputs_padded.dim() != 3:
+        raise RuntimeError("inputs_padded must be a 3-dimensional tensor")
+    _contig(inputs_padded, "inputs_padded")
+    _contig(first_idxs, "first_idxs")
+    B, M, D = inputs_padded.shape
+    with torch.cuda.device(dev):
+        out = torch.empty((int(num_inputs), D), dtype=torch.float32, device=dev)
+        _check(
+            _lib.pointops_padded_to_packed(inputs_padded.data_ptr(), first_idxs.data_ptr(),
+                                           int(num_inputs), B, M, D, out.data_ptr(), _stream()),
+            "padded_to_packed",
+        )
+    return out
+
+
+# --- device halves of knn_gather / masked_gather (functions/knn.py:200-250) -------
+def gather_neighbors(x, idx, lengths=None):
+    dev = _require_gpu(x, idx) if lengths is None else _require_gpu(x, idx, lengths)
+    x, idx = x.contiguous(), idx.contiguous()
+    N, M, U = x.shape
+    _, L, K = idx.shape
+    with torch.cuda.device(dev):
+        out = torch.empty((N, L, K, U), dtype=torch.float32, device=dev)
+        _check(
+            _lib.pointops_gather_neighbors(x.data_ptr(), idx.data_ptr(),
+                                           lengths.contiguous().data_ptr() if lengths is not None else None,
+                                           N, M, U, L, K, out.data_ptr(), _stream()),
+            "gather_neighbors",
+        )
+    return out
+
+
+def gather_neighbors_backward(grad_out, idx, lengths, M: int):
+    dev = _require_gpu(grad_out, idx)
+    grad_out, idx = grad_out.contiguous(), idx.contiguous()
+    N, L, K, U = grad_out.shape
+    with torch.cuda.device(dev):
+        grad_x = torch.empty((N, M, U), dtype=torch.float32, device=dev)
+        _check(
+            _lib.pointops_gather_neighbors_backward(
+                grad_out.data_ptr(), idx.data_ptr(),
+                lengths.contiguous().data_ptr() if lengths is not None else None, N, M, U, L, K,
+                grad_x.data_ptr(), _stream()),
+            "gather_neighbors_backward",
+        )
+    return grad_x
+
+
+def chamfer_reduce(dists, lengths, weights, mean: bool):
+    """dists (N,P) fp32 -> (N,) per-cloud masked sum [* weights] [/ max(len,1)]."""
+    dev = _require_gpu(dists, lengths)
+    dists, lengths = dists.contiguous(), lengths.contiguous()
+    N, P = dists.shape
+    with torch.cuda.device(dev):
+        out = torch.empty((N,), dtype=torch.float32, device=dev)
+        _check(
+            _lib.pointops_chamfer_reduce(dists.data_ptr(), lengths.data_ptr(),
+                                         weights.contiguous().data_ptr() if weights is not None else None,
+                                         N, P, int(bool(mean)), out.data_ptr(), _stream()),
+            "chamfer_reduce",
+        )
+    return out

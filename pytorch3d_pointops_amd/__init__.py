@@ -1,0 +1,10 @@
+"""pytorch3d_pointops_amd -- MI355X-native (gfx950) batched point-cloud neighbour ops.
+
+Drop-in for the hot path of ``pytorch3d_pointops`` (knn_points, knn_gather,
+ball_query, sample_farthest_points, chamfer_distance, packed_to_padded /
+padded_to_packed) behind the same ``functions.*`` Python API; the device work is
+done by hand-written HIP kernels in ``lib/libpointops_amd.so`` reached through a
+C ABI (``include/pointops_amd.h``).  There is no CPU fallback: a missing library
+or a CPU tensor raises.
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,145 @@
+// ball_query.hip -- first-K-within-radius neighbour search for gfx950.
+//
+// Replaces BallQuery (reference: csrc/ball_query/ball_query.h:62-93) with the CPU
+// path's semantics (csrc/ball_query/ball_query_cpu.cpp:12-54): for each query the
+// first K points of p2 in INDEX order with dist2 < radius*radius (strict, fp32
+// product), idx padded with -1 and dists with 0 (also for rows >= lengths1[n]).
+//
+// One lane per query; p2 is streamed through the scalar path exactly as in
+// knn.hip (wave-uniform address -> s_load -> SGPR operands).  A wave stops
+// scanning as soon as all of its 64 queries are full (wave-uniform early exit via
+// ballot), which on dense clouds is after ~1 % of p2: the
+// op is then bound by writing the (N,P1,K) outputs.
+#include "common.h"
+
+namespace pointops {
+
+constexpr int kBqBlock = 256;
+constexpr int kBqTile = 8;
+
+template <int DT>
+__global__ __launch_bounds__(kBqBlock) void ball_query_kernel(
+    const float* __restrict__ p1, const float* __restrict__ p2,
+    const int64_t* __restrict__ lengths1, const int64_t* __restrict__ lengths2, int P1, int P2,
+    int Drt, int K, float radius2, int tiles_per_cloud, int64_t* __restrict__ idxs,
+    float* __restrict__ dists) {
+  const int D = DT > 0 ? DT : Drt;
+  const int n = blockIdx.x / tiles_per_cloud;
+  const int tile = blockIdx.x - n * tiles_per_cloud;
+  const int i = tile * kBqBlock + threadIdx.x;
+  const bool in_range = i < P1;
+  const int len1 = (int)lengths1[n];
+  int len2 = (int)lengths2[n];
+  if (len2 > P2) len2 = P2;
+  const int64_t row = (int64_t)n * P1 + (in_range ? i : 0);
+  int64_t* __restrict__ orow_i = idxs + row * K;
+  float* __restrict__ orow_d = dists + row * K;
+  const bool active = in_range && i < len1;
+  int count = 0;
+  const float* __restrict__ q = p2 + (int64_t)n * P2 * D;
+
+  if constexpr (DT > 0) {
+    float a[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) a[d] = active ? p1[row * DT + d] : 0.0f;
+    int j = 0;
+    // wave-uniform loop: exit when every lane of the wave is full or inactive
+    while (j < len2 && __any(active && count < K)) {
+      if (j + kBqTile <= len2) {
+        float t[kBqTile * DT];
+#pragma unroll
+        for (int u = 0; u < kBqTile * DT; ++u) t[u] = q[(int64_t)j * DT + u];
+#pragma unroll
+        for (int jj = 0; jj < kBqTile; ++jj) {
+          float acc;
+          {
+            const float diff = a[0] - t[jj * DT];
+            acc = diff * diff;
+          }
+#pragma unroll
+          for (int d = 1; d < DT; ++d) {
+            const float diff = a[d] - t[jj * DT + d];
+            acc = acc + diff * diff;
+          }
+          if (active && count < K && acc < radius2) {
+            orow_i[count] = j + jj;
+            orow_d[count] = acc;
+            ++count;
+          }
+        }
+        j += kBqTile;
+      } else {
+        float acc;
+        {
+          const float diff = a[0] - q[(int64_t)j * DT];
+          acc = diff * diff;
+        }
+#pragma unroll
+        for (int d = 1; d < DT; ++d) {
+          const float diff = a[d] - q[(int64_t)j * DT + d];
+          acc = acc + diff * diff;
+        }
+        if (active && count < K && acc < radius2) {
+          orow_i[count] = j;
+          orow_d[count] = acc;
+          ++count;
+        }
+        ++j;
+      }
+    }
+  } else {
+    if (active) {
+      const float* __restrict__ a = p1 + row * D;
+      for (int j = 0; j < len2 && count < K; ++j) {
+        const float* __restrict__ b = q + (int64_t)j * D;
+        float acc = 0.0f;
+        for (int d = 0; d < D; ++d) {
+          const float diff = a[d] - b[d];
+          acc = acc + diff * diff;
+        }
+        if (acc < radius2) {
+          orow_i[count] = j;
+          orow_d[count] = acc;
+          ++count;
+        }
+      }
+    }
+  }
+  if (in_range) {
+    for (int k = count; k < K; ++k) {
+      orow_i[k] = -1;
+      orow_d[k] = 0.0f;
+    }
+  }
+}
+
+}  // namespace pointops
+
+using namespace pointops;
+
+extern "C" int pointops_ball_query(const float* p1, const float* p2, const int64_t* lengths1,
+                                   const int64_t* lengths2, int64_t N, int64_t P1, int64_t P2,
+                                   int64_t D, int64_t K, float radius, int64_t* idxs, float* dists,
+                                   void* stream_) {
+  POINTOPS_REQUIRE(N >= 0 && P1 >= 0 && P2 >= 0 && D >= 1 && K >= 0, "ball_query: bad sizes");
+  POINTOPS_REQUIRE(P1 < (1LL << 31) && P2 < (1LL << 31) && K < (1LL << 31) && D < (1LL << 16),
+                   "ball_query: sizes must fit int32");
+  if (N == 0 || P1 == 0 || K == 0) return POINTOPS_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const float radius2 = radius * radius;  // fp32 product (ball_query_cpu.cpp:26)
+  const int tiles = (int)ceil_div(P1, kBqBlock);
+  POINTOPS_REQUIRE(N * tiles < (1LL << 31), "ball_query: grid too large");
+  const dim3 grid((unsigned)(N * tiles)), block(kBqBlock);
+#define PO_LAUNCH(DT)                                                                            \
+  hipLaunchKernelGGL((ball_query_kernel<DT>), grid, block, 0, stream, p1, p2, lengths1, lengths2, \
+                     (int)P1, (int)P2, (int)D, (int)K, radius2, tiles, idxs, dists)
+  switch (D) {
+    case 1: PO_LAUNCH(1); break;
+    case 2: PO_LAUNCH(2); break;
+    case 3: PO_LAUNCH(3); break;
+    case 4: PO_LAUNCH(4); break;
+    default: PO_LAUNCH(0); break;
+  }
+#undef PO_LAUNCH
+  return check_launch("ball_query");
+}

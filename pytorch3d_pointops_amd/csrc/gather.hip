@@ -1,0 +1,84 @@
+// gather.hip -- neighbour gather and its scatter-add backward for gfx950.
+//
+// Device half of knn_gather / masked_gather (reference: functions/knn.py:200-250,
+// functions/utils.py:20-65): out[n,l,k,:] = x[n, idx[n,l,k], :], zero where
+// k >= lengths[n] (knn padding) or idx < 0 (ball-query / FPS -1 padding).  The
+// reference builds this from expand + torch.gather, which materialises an
+// (N,L,K,U) int64 index (8*U bytes per output element); here the index is read
+// once per (n,l,k) row and the output is written coalesced, one lane per element.
+// Backward scatters grad_out into grad_x with fp32 atomics (same masks).
+#include "common.h"
+
+namespace pointops {
+
+constexpr int kGaBlock = 256;
+
+__global__ __launch_bounds__(kGaBlock) void gather_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ idx,
+    const int64_t* __restrict__ lengths, int64_t total, int64_t M, int U, int64_t LK, int K,
+    float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * kGaBlock + threadIdx.x;
+  if (e >= total) return;
+  const int64_t r = e / U;  // (n,l,k) row
+  const int u = (int)(e - r * U);
+  const int64_t n = r / LK;
+  const int k = (int)(r % K);
+  const int64_t j = idx[r];
+  bool ok = j >= 0 && j < M;
+  if (lengths != nullptr) ok = ok && (int64_t)k < lengths[n];
+  out[e] = ok ? x[(n * M + j) * U + u] : 0.0f;
+}
+
+__global__ __launch_bounds__(kGaBlock) void gather_backward_kernel(
+    const float* __restrict__ grad_out, const int64_t* __restrict__ idx,
+    const int64_t* __restrict__ lengths, int64_t total, int64_t M, int U, int64_t LK, int K,
+    float* __restrict__ grad_x) {
+  const int64_t e = (int64_t)blockIdx.x * kGaBlock + threadIdx.x;
+  if (e >= total) return;
+  const int64_t r = e / U;
+  const int u = (int)(e - r * U);
+  const int64_t n = r / LK;
+  const int k = (int)(r % K);
+  const int64_t j = idx[r];
+  bool ok = j >= 0 && j < M;
+  if (lengths != nullptr) ok = ok && (int64_t)k < lengths[n];
+  if (ok) atomicAdd(grad_x + (n * M + j) * U + u, grad_out[e]);
+}
+
+}  // namespace pointops
+
+using namespace pointops;
+
+extern "C" int pointops_gather_neighbors(const float* x, const int64_t* idx, const int64_t* lengths,
+                                         int64_t N, int64_t M, int64_t U, int64_t L, int64_t K,
+                                         float* out, void* stream_) {
+  POINTOPS_REQUIRE(N >= 0 && M >= 0 && U >= 1 && L >= 0 && K >= 0 && U < (1LL << 31) && K < (1LL << 31),
+                   "gather_neighbors: bad sizes");
+  const int64_t total = N * L * K * U;
+  if (total == 0) return POINTOPS_OK;
+  const int64_t blocks = ceil_div(total, kGaBlock);
+  POINTOPS_REQUIRE(blocks < (1LL << 31), "gather_neighbors: grid too large");
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)blocks), dim3(kGaBlock), 0, (hipStream_t)stream_, x,
+                     idx, lengths, total, M, (int)U, L * K, (int)K, out);
+  return check_launch("gather_neighbors");
+}
+
+extern "C" int pointops_gather_neighbors_backward(const float* grad_out, const int64_t* idx,
+                                                  const int64_t* lengths, int64_t N, int64_t M,
+                                                  int64_t U, int64_t L, int64_t K, float* grad_x,
+                                                  void* stream_) {
+  POINTOPS_REQUIRE(N >= 0 && M >= 0 && U >= 1 && L >= 0 && K >= 0 && U < (1LL << 31) && K < (1LL << 31),
+                   "gather_neighbors_backward: bad sizes");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N * M * U > 0) {
+    if (hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)(N * M * U), stream) != hipSuccess)
+      return check_launch("gather_neighbors_backward(memset)");
+  }
+  const int64_t total = N * L * K * U;
+  if (total == 0) return POINTOPS_OK;
+  const int64_t blocks = ceil_div(total, kGaBlock);
+  POINTOPS_REQUIRE(blocks < (1LL << 31), "gather_neighbors_backward: grid too large");
+  hipLaunchKernelGGL(gather_backward_kernel, dim3((unsigned)blocks), dim3(kGaBlock), 0, stream,
+                     grad_out, idx, lengths, total, M, (int)U, L * K, (int)K, grad_x);
+  return check_launch("gather_neighbors_backward");
+}

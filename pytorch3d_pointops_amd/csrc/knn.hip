@@ -1,0 +1,301 @@
+// knn.hip -- exact brute-force K nearest neighbours for gfx950 (MI355X).
+//
+// Replaces KNearestNeighborIdx (reference: csrc/knn/knn.h:59-80) with the CPU
+// path's semantics (csrc/knn/knn_cpu.cpp:13-69): the K smallest (dist, idx)
+// pairs per query in ascending lexicographic order, unfused fp32 arithmetic,
+// zeros for padded rows/slots.  This is NOT the reference's CUDA design (fixed
+// 256x256 grid, every thread streaming p2 from global memory, MinK that evicts
+// the lower index on ties): see DESIGN.md section "KNN".
+//
+// Design (one lane = one query point, wave64):
+//   * the query point lives in VGPRs; every lane of a wave consumes the SAME p2
+//     point, so p2 is fetched through the scalar path (s_load_dwordx8/x16 from a
+//     wave-uniform address into SGPRs, served by the scalar cache / L2) and used
+//     directly as the SGPR operand of v_sub_f32 -- no LDS traffic, no VGPRs, no
+//     per-lane address arithmetic for the streamed cloud;
+//   * the running top-K is a sorted register array (K compile-time).  A candidate
+//     is compared once against the K-th best (strict <, so an equal-distance
+//     newcomer -- which always has the larger index because p2 is scanned in
+//     index order -- never displaces: exactly std::priority_queue<tuple> order);
+//     the insert shifts with v_cndmask chains and places the newcomer AFTER equal
+//     keys, so the list is always in (dist, idx) order and is emitted as is: the
+//     reference's separate sort + gather pass (functions/knn.py:77-89) is not needed;
+//   * grid = clouds x ceil(P1/256) workgroups of 256 lanes (>> 256 CUs at the
+//     bench sizes); all workgroups of a cloud re-stream the same 12*P2 bytes,
+//     which stay L2/Infinity-Cache resident (786 KB per cloud at P2=65536).
+#include "common.h"
+
+namespace pointops {
+
+// ---------------------------------------------------------------------------
+// distance helpers (unfused; see common.h)
+// ---------------------------------------------------------------------------
+template <int D, int NORM>
+__device__ __forceinline__ float pair_dist(const float (&a)[D], const float* __restrict__ b) {
+  float acc;
+  {
+    const float diff = a[0] - b[0];
+    acc = (NORM == 1) ? __builtin_fabsf(diff) : diff * diff;
+  }
+#pragma unroll
+  for (int d = 1; d < D; ++d) {
+    const float diff = a[d] - b[d];
+    acc = (NORM == 1) ? (acc + __builtin_fabsf(diff)) : (acc + diff * diff);
+  }
+  return acc;
+}
+
+// Sorted (ascending) register top-K.  insert() requires d < dk[KC-1].
+template <int KC>
+struct TopK {
+  float dk[KC];
+  int ik[KC];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+      dk[i] = __builtin_inff();
+      ik[i] = 0;
+    }
+  }
+  __device__ __forceinline__ float worst() const { return dk[KC - 1]; }
+  __device__ __forceinline__ void insert(float d, int j) {
+#pragma unroll
+    for (int i = KC - 1; i > 0; --i) {
+      const bool up = d < dk[i - 1];  // element i-1 moves up to slot i
+      const bool here = d < dk[i];    // newcomer lands at or below slot i
+      dk[i] = up ? dk[i - 1] : (here ? d : dk[i]);
+      ik[i] = up ? ik[i - 1] : (here ? j : ik[i]);
+    }
+    if (d < dk[0]) {
+      dk[0] = d;
+      ik[0] = j;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Register kernel: D in [1,8], K <= KC <= 32.
+// ---------------------------------------------------------------------------
+constexpr int kKnnBlock = 256;
+constexpr int kTileP2 = 8;  // p2 points fetched per scalar-load group
+
+template <int D, int KC, int NORM>
+__global__ __launch_bounds__(kKnnBlock) void knn_reg_kernel(
+    const float* __restrict__ p1, const float* __restrict__ p2,
+    const int64_t* __restrict__ lengths1, const int64_t* __restrict__ lengths2, int P1, int P2,
+    int K, int tiles_per_cloud, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+  const int n = blockIdx.x / tiles_per_cloud;  // wave-uniform
+  const int tile = blockIdx.x - n * tiles_per_cloud;
+  const int i = tile * kKnnBlock + threadIdx.x;
+  if (i >= P1) return;
+  const int len1 = (int)lengths1[n];
+  int len2 = (int)lengths2[n];
+  if (len2 > P2) len2 = P2;
+  if (len2 < 0) len2 = 0;
+  const int64_t row = (int64_t)n * P1 + i;
+  int64_t* __restrict__ orow_i = idxs + row * K;
+  float* __restrict__ orow_d = dists + row * K;
+
+  if (i >= len1) {  // padded query row: zeros (knn_cpu.cpp:25-26)
+    for (int k = 0; k < K; ++k) {
+      orow_i[k] = 0;
+      orow_d[k] = 0.0f;
+    }
+    return;
+  }
+
+  float a[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) a[d] = p1[row * D + d];
+
+  TopK<KC> top;
+  top.init();
+
+  const float* __restrict__ q = p2 + (int64_t)n * P2 * D;  // wave-uniform base
+  int j = 0;
+  for (; j + kTileP2 <= len2; j += kTileP2) {
+    float t[kTileP2 * D];
+#pragma unroll
+    for (int u = 0; u < kTileP2 * D; ++u) t[u] = q[(int64_t)j * D + u];  // uniform -> s_load
+#pragma unroll
+    for (int jj = 0; jj < kTileP2; ++jj) {
+      const float dist = pair_dist<D, NORM>(a, t + jj * D);
+      if (dist < top.worst()) top.insert(dist, j + jj);
+    }
+  }
+  for (; j < len2; ++j) {
+    float t[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u) t[u] = q[(int64_t)j * D + u];
+    const float dist = pair_dist<D, NORM>(a, t);
+    if (dist < top.worst()) top.insert(dist, j);
+  }
+
+  const int kvalid = len2 < K ? len2 : K;
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    if (k < K) {
+      const bool ok = k < kvalid;
+      orow_i[k] = ok ? (int64_t)top.ik[k] : 0;
+      orow_d[k] = ok ? top.dk[k] : 0.0f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Generic kernel: any D, any K.  The sorted list lives in the output rows
+// themselves (private to the thread), the query is re-read from global memory
+// (L1-resident).  Correctness fallback for D > 8 or K > 32.
+// ---------------------------------------------------------------------------
+template <int NORM>
+__global__ __launch_bounds__(kKnnBlock) void knn_generic_kernel(
+    const float* __restrict__ p1, const float* __restrict__ p2,
+    const int64_t* __restrict__ lengths1, const int64_t* __restrict__ lengths2, int P1, int P2,
+    int D, int K, int tiles_per_cloud, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+  const int n = blockIdx.x / tiles_per_cloud;
+  const int tile = blockIdx.x - n * tiles_per_cloud;
+  const int i = tile * kKnnBlock + threadIdx.x;
+  if (i >= P1) return;
+  const int len1 = (int)lengths1[n];
+  int len2 = (int)lengths2[n];
+  if (len2 > P2) len2 = P2;
+  if (len2 < 0) len2 = 0;
+  const int64_t row = (int64_t)n * P1 + i;
+  int64_t* orow_i = idxs + row * K;
+  float* orow_d = dists + row * K;
+  int cnt = 0;
+  if (i < len1) {
+    const float* a = p1 + row * D;
+    const float* q = p2 + (int64_t)n * P2 * D;
+    float worst = __builtin_inff();
+    for (int j = 0; j < len2; ++j) {
+      const float* b = q + (int64_t)j * D;
+      float acc = 0.0f;
+      for (int d = 0; d < D; ++d) {
+        const float diff = a[d] - b[d];
+        acc = (NORM == 1) ? (acc + __builtin_fabsf(diff)) : (acc + diff * diff);
+      }
+      if (cnt < K || acc < worst) {
+        int pos = cnt < K ? cnt : K - 1;  // slot that is freed / appended
+        while (pos > 0 && acc < orow_d[pos - 1]) {
+          orow_d[pos] = orow_d[pos - 1];
+          orow_i[pos] = orow_i[pos - 1];
+          --pos;
+        }
+        orow_d[pos] = acc;
+        orow_i[pos] = j;
+        if (cnt < K) ++cnt;
+        if (cnt == K) worst = orow_d[K - 1];
+      }
+    }
+  }
+  for (int k = cnt; k < K; ++k) {
+    orow_i[k] = 0;
+    orow_d[k] = 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host dispatch
+// ---------------------------------------------------------------------------
+struct KnnArgs {
+  const float *p1, *p2;
+  const int64_t *l1, *l2;
+  int P1, P2, D, K, tiles;
+  int64_t N;
+  int64_t* idxs;
+  float* dists;
+  hipStream_t stream;
+};
+
+template <int D, int KC, int NORM>
+static void launch_reg(const KnnArgs& a) {
+  const dim3 grid((unsigned)(a.N * a.tiles));
+  hipLaunchKernelGGL((knn_reg_kernel<D, KC, NORM>), grid, dim3(kKnnBlock), 0, a.stream, a.p1, a.p2,
+                     a.l1, a.l2, a.P1, a.P2, a.K, a.tiles, a.idxs, a.dists);
+}
+
+template <int D, int NORM>
+static void dispatch_k(const KnnArgs& a) {
+  const int K = a.K;
+  if (K <= 1) launch_reg<D, 1, NORM>(a);
+  else if (K <= 2) launch_reg<D, 2, NORM>(a);
+  else if (K <= 4) launch_reg<D, 4, NORM>(a);
+  else if (K <= 8) launch_reg<D, 8, NORM>(a);
+  else if (K <= 16) launch_reg<D, 16, NORM>(a);
+  else if (K <= 24) launch_reg<D, 24, NORM>(a);
+  else launch_reg<D, 32, NORM>(a);
+}
+
+template <int NORM>
+static void dispatch_d(const KnnArgs& a) {
+  switch (a.D) {
+    case 1: dispatch_k<1, NORM>(a); break;
+    case 2: dispatch_k<2, NORM>(a); break;
+    case 3: dispatch_k<3, NORM>(a); break;
+    case 4: dispatch_k<4, NORM>(a); break;
+    case 5: dispatch_k<5, NORM>(a); break;
+    case 6: dispatch_k<6, NORM>(a); break;
+    case 7: dispatch_k<7, NORM>(a); break;
+    case 8: dispatch_k<8, NORM>(a); break;
+    default: break;
+  }
+}
+
+}  // namespace pointops
+
+using namespace pointops;
+
+extern "C" {
+
+int pointops_knn_check_version(int version, int64_t D, int64_t K) {
+  // Kernel families of this library (the reference's V0..V3 map onto them the
+  // same way: the highest valid version is the fastest; csrc/knn/knn.cu:292-312):
+  //   0 generic (any D, K)   1/2/3 register top-K (D in [1,8], K in [1,32])
+  if (version == 0) return 1;
+  if (version >= 1 && version <= 3) return (D >= 1 && D <= 8 && K >= 1 && K <= 32) ? 1 : 0;
+  return 0;
+}
+
+size_t pointops_knn_workspace_bytes(int64_t, int64_t, int64_t, int64_t, int64_t, int) { return 0; }
+
+int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* lengths1,
+                            const int64_t* lengths2, int64_t N, int64_t P1, int64_t P2, int64_t D,
+                            int norm, int64_t K, int version, int64_t* idxs, float* dists,
+                            void* /*workspace*/, size_t /*workspace_bytes*/, void* stream) {
+  POINTOPS_REQUIRE(norm == 1 || norm == 2, "knn_points_idx: norm must be 1 or 2 (got %d)", norm);
+  POINTOPS_REQUIRE(N >= 0 && P1 >= 0 && P2 >= 0 && D >= 1 && K >= 1,
+                   "knn_points_idx: bad sizes N=%lld P1=%lld P2=%lld D=%lld K=%lld", (long long)N,
+                   (long long)P1, (long long)P2, (long long)D, (long long)K);
+  POINTOPS_REQUIRE(P1 < (1LL << 31) && P2 < (1LL << 31) && K < (1LL << 20) && D < (1LL << 16),
+                   "knn_points_idx: P1/P2 must fit int32");
+  if (N == 0 || P1 == 0) return POINTOPS_OK;
+  POINTOPS_REQUIRE(p1 && p2 && lengths1 && lengths2 && idxs && dists,
+                   "knn_points_idx: null pointer");
+  KnnArgs a;
+  a.p1 = p1; a.p2 = p2; a.l1 = lengths1; a.l2 = lengths2;
+  a.P1 = (int)P1; a.P2 = (int)P2; a.D = (int)D; a.K = (int)K; a.N = N;
+  a.tiles = (int)ceil_div(P1, kKnnBlock);
+  a.idxs = idxs; a.dists = dists; a.stream = (hipStream_t)stream;
+  POINTOPS_REQUIRE(N * a.tiles < (1LL << 31), "knn_points_idx: grid too large");
+
+  int v = version;
+  if (v < 0 || v > 3 || !pointops_knn_check_version(v, D, K)) {
+    v = pointops_knn_check_version(3, D, K) ? 3 : 0;  // like ChooseVersion (knn.cu:305-312)
+  }
+  if (v == 0) {
+    const dim3 grid((unsigned)(N * a.tiles));
+    if (norm == 1)
+      hipLaunchKernelGGL(knn_generic_kernel<1>, grid, dim3(kKnnBlock), 0, a.stream, p1, p2, lengths1,
+                         lengths2, a.P1, a.P2, a.D, a.K, a.tiles, idxs, dists);
+    else
+      hipLaunchKernelGGL(knn_generic_kernel<2>, grid, dim3(kKnnBlock), 0, a.stream, p1, p2, lengths1,
+                         lengths2, a.P1, a.P2, a.D, a.K, a.tiles, idxs, dists);
+  } else {
+    if (norm == 1) dispatch_d<1>(a);
+    else dispatch_d<2>(a);
+  }
+  return check_launch("knn_points_idx");
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+"""masked_gather, wmean, get_point_covariances -- API of the reference's functions/utils.py.
+
+reference: pytorch3d_pointops/functions/utils.py:20-65 (masked_gather), :68-108
+(wmean), :111-153 (get_point_covariances).
+"""
+from typing import Optional, Tuple, Union
+
+import torch
+
+
+def masked_gather(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """Gather ``points`` (N,P,D) at ``idx`` (N,K) or (N,P',K) where -1 marks padding.
+
+    Same contract as the reference (functions/utils.py:20-65): padded entries give
+    0.0; differentiable w.r.t. ``points``.  Runs the fused HIP gather kernel
+    (idx < 0 -> 0) instead of clone + masked index + torch.gather + masked fill.
+    """
+    from .knn import _gather_neighbors
+
+    if len(idx) != len(points):
+        raise ValueError("points and idx must have the same batch dimension")
+    if idx.ndim == 3:
+        if points.dtype != torch.float32:
+            return _masked_gather_torch(points, idx)
+        return _gather_neighbors.apply(points, idx, None)
+    elif idx.ndim == 2:
+        if points.dtype != torch.float32:
+            return _masked_gather_torch(points, idx)
+        return _gather_neighbors.apply(points, idx[:, :, None], None)[:, :, 0, :]
+    else:
+        raise ValueError("idx format is not supported %s" % repr(idx.shape))
+
+
+def _masked_gather_torch(points, idx):
+    N, P, D = points.shape
+    mask = idx.eq(-1)
+    safe = idx.masked_fill(mask, 0)
+    if idx.ndim == 3:
+        K = idx.shape[2]
+        out = points[:, :, None, :].expand(-1, -1, K, -1).gather(1, safe[..., None].expand(-1, -1, -1, D))
+    else:
+        out = points.gather(1, safe[..., None].expand(-1, -1, D))
+    return out.masked_fill(mask[..., None], 0.0)
+
+
+def wmean(
+    x: torch.Tensor,
+    weight: Optional[torch.Tensor] = None,
+    dim: Union[int, Tuple[int]] = -2,
+    keepdim: bool = True,
+    eps: float = 1e-9,
+) -> torch.Tensor:
+    """(Weighted) mean over ``dim``; reference: functions/utils.py:68-108."""
+    args = {"dim": dim, "keepdim": keepdim}
+    if weight is None:
+        return x.mean(**args)
+    if any(xd != wd and xd != 1 and wd != 1 for xd, wd in zip(x.shape[-2::-1], weight.shape[::-1])):
+        raise ValueError("wmean: weights are not compatible with the tensor")
+    return (x * weight[..., None]).sum(**args) / weight[..., None].sum(**args).clamp(eps)
+
+
+def get_point_covariances(
+    points_padded: torch.Tensor,
+    num_points_per_cloud: torch.Tensor,
+    neighborhood_size: int,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-point covariance of the K nearest neighbours; reference: functions/utils.py:111-153."""
+    from .knn import knn_points
+
+    k_nearest_neighbors = knn_points(
+        points_padded,
+        points_padded,
+        lengths1=num_points_per_cloud,
+        lengths2=num_points_per_cloud,
+        K=neighborhood_size,
+        return_nn=True,
+    ).knn
+    pt_mean = k_nearest_neighbors.mean(2, keepdim=True)
+    central_diff = k_nearest_neighbors - pt_mean
+    per_pt_cov = central_diff.unsqueeze(4) * central_diff.unsqueeze(3)
+    covariances = per_pt_cov.mean(2)
+    return covariances, k_nearest_neighbors

@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz FROM THE REFERENCE ITSELF (build container only).
+
+What runs here: the reference's Python wrappers imported from /root/reference
+(`pytorch3d_pointops.functions.*`, `pytorch3d_pointops.structures.Pointclouds`)
+on top of the reference's own CPU kernels compiled by oracle/build_ref.py into
+oracle/_ref/_C*.so -- nothing from this repository's product or oracle code is
+involved in producing the expected outputs.  Inputs come from tests/cases.py
+(seeded, regenerable anywhere), so the fixtures hold only outputs (+ digests).
+
+    python tests/golden/make_golden.py            # small fixtures (seconds)
+    python tests/golden/make_golden.py --big      # + cfg2-size single-cloud digests (~1 min)
+
+The reference cannot travel to the GPU box; these fixtures are what pins parity there.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle.build_ref import build as build_ref, OUT_DIR as REF_DIR  # noqa: E402
+
+build_ref(verbose=True)
+sys.path.insert(0, "/root/reference")
+import pytorch3d_pointops  # noqa: E402  (reference package; __init__ only sets __version__)
+
+pytorch3d_pointops.__path__.append(REF_DIR)  # lets `from pytorch3d_pointops import _C` find oracle/_ref/_C*.so
+from pytorch3d_pointops import _C as ref_C  # noqa: E402
+from pytorch3d_pointops.functions import (  # noqa: E402
+    ball_query, knn_gather, knn_points, packed_to_padded, padded_to_packed, sample_farthest_points, masked_gather)
+from pytorch3d_pointops.functions.chamfer import chamfer_distance  # noqa: E402
+from pytorch3d_pointops.functions.sample_farthest_points import sample_farthest_points_naive  # noqa: E402
+from pytorch3d_pointops.structures import Pointclouds  # noqa: E402
+
+import cases  # noqa: E402
+from pytorch3d_pointops_amd import synth  # noqa: E402  (input generator only)
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t if dtype is None else t.to(dtype)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({os.path.getsize(path)} B, {len(arrays)} arrays)")
+
+
+def gen_knn():
+    out = {}
+    for name, c in cases.knn_cases().items():
+        r = knn_points(T(c["p1"]), T(c["p2"]), T(c["l1"], torch.int64), T(c["l2"], torch.int64),
+                       norm=c["norm"], K=c["K"], return_nn=True)
+        out[name + "/dists"] = r.dists.numpy()
+        out[name + "/idx"] = r.idx.numpy().astype(np.int32)
+        out[name + "/knn"] = r.knn.numpy()
+        # the raw operator (no python-side sort) must agree with the wrapper on CPU
+        i2, d2 = ref_C.knn_points_idx(T(c["p1"]), T(c["p2"]), T(c["l1"], torch.int64), T(c["l2"], torch.int64),
+                                      c["norm"], c["K"], -1)
+        assert torch.equal(i2, r.idx) and torch.equal(d2, r.dists), name
+    save("knn", **out)
+
+
+def gen_knn_backward():
+    out = {}
+    for name, c in cases.knn_backward_cases().items():
+        p1 = T(c["p1"]).requires_grad_(True)
+        p2 = T(c["p2"]).requires_grad_(True)
+        r = knn_points(p1, p2, T(c["l1"], torch.int64), T(c["l2"], torch.int64), norm=c["norm"], K=c["K"])
+        g = T(cases.grad_for(name, tuple(r.dists.shape)))
+        r.dists.backward(g)
+        out[name + "/grad_p1"] = p1.grad.numpy()
+        out[name + "/grad_p2"] = p2.grad.numpy()
+    save("knn_backward", **out)
+
+
+def gen_ball_query():
+    out = {}
+    for name, c in cases.ball_query_cases().items():
+        p1 = T(c["p1"]).requires_grad_(True)
+        p2 = T(c["p2"]).requires_grad_(True)
+        r = ball_query(p1, p2, T(c["l1"], torch.int64), T(c["l2"], torch.int64), K=c["K"], radius=c["radius"],
+                       return_nn=True)
+        out[name + "/dists"] = r.dists.detach().numpy()
+        out[name + "/idx"] = r.idx.numpy().astype(np.int32)
+        out[name + "/knn"] = r.knn.detach().numpy()
+        g = T(cases.grad_for("bq" + name, tuple(r.dists.shape)))
+        (r.dists * g).sum().backward()
+        out[name + "/grad_p1"] = p1.grad.numpy()
+        out[name + "/grad_p2"] = p2.grad.numpy()
+    save("ball_query", **out)
+
+
+def gen_fps():
+    out = {}
+    for name, c in cases.fps_cases().items():
+        pts = T(c["points"])
+        idx = ref_C.sample_farthest_points(pts, T(c["lengths"], torch.int64), T(c["K"], torch.int64),
+                                           T(c["start"], torch.int64))
+        out[name + "/idx"] = idx.numpy().astype(np.int32)
+        out[name + "/points"] = masked_gather(pts, idx).numpy()
+        if (c["start"] == 0).all():
+            # wrapper path (start 0) and the reference's pure-torch naive variant must agree
+            sp, si = sample_farthest_points(pts, T(c["lengths"], torch.int64), T(c["K"], torch.int64))
+            assert torch.equal(si, idx), name
+            if name != "all_equal":
+                _, ni = sample_farthest_points_naive(pts, T(c["lengths"], torch.int64), T(c["K"], torch.int64))
+                assert torch.equal(ni, idx), name
+    save("fps", **out)
+
+
+def gen_packed():
+    out = {}
+    for name, c in cases.packed_cases().items():
+        x, first, F = cases.packed_inputs(c)
+        xt = T(x).requires_grad_(True)
+        arg = xt[:, 0] if c["D"] == 1 else xt
+        padded = packed_to_padded(arg, T(first), int(c["max_size"]))
+        out[name + "/padded"] = padded.detach().numpy()
+        g = T(cases.grad_for("pp" + name, tuple(padded.shape)))
+        (padded * g).sum().backward()
+        out[name + "/grad_packed"] = xt.grad.numpy()
+        back = padded_to_packed(padded.detach(), T(first), F)
+        out[name + "/roundtrip"] = back.numpy()
+        # padded -> packed of an arbitrary padded tensor (padding NOT zero) + its gradient
+        pt = T(cases.grad_for("pq" + name, tuple(padded.shape))).requires_grad_(True)
+        pk = padded_to_packed(pt, T(first), F)
+        out[name + "/packed_of_g"] = pk.detach().numpy()
+        pk.sum().backward()
+        out[name + "/grad_padded_ones"] = pt.grad.numpy()
+    # 3-D trailing dims through the wrapper
+    x = cases.cloud(410, (15, 2, 3))
+    first = np.array([0, 5, 5, 12], np.int64)
+    p3 = packed_to_padded(T(x), T(first), 7)
+    out["trailing/padded"] = p3.numpy()
+    out["trailing/roundtrip"] = padded_to_packed(p3, T(first), 15).numpy()
+    save("packed_padded", **out)
+
+
+def gen_gather():
+    out = {}
+    x = T(cases.cloud(601, (2, 50, 5)))
+    idx = T(synth.randint(602, 0, 49, (2, 30, 4)))
+    lengths = T(np.array([50, 2]), torch.int64)
+    xr = x.clone().requires_grad_(True)
+    o = knn_gather(xr, idx, lengths)
+    out["knn_gather/out"] = o.detach().numpy()
+    g = T(cases.grad_for("kg", tuple(o.shape)))
+    (o * g).sum().backward()
+    out["knn_gather/grad_x"] = xr.grad.numpy()
+    midx = idx.clone()
+    midx[0, ::3, 1] = -1
+    midx[1, :, 3] = -1
+    xr2 = x.clone().requires_grad_(True)
+    o2 = masked_gather(xr2, midx)
+    out["masked_gather3/out"] = o2.detach().numpy()
+    (o2 * g).sum().backward()
+    out["masked_gather3/grad_x"] = xr2.grad.numpy()
+    m2 = midx[:, :, 1].contiguous()
+    out["masked_gather2/out"] = masked_gather(x, m2).numpy()
+    save("gather", **out)
+
+
+def gen_chamfer():
+    out = {}
+    inp = cases.chamfer_inputs()
+    for v in cases.chamfer_variants():
+        key = cases.variant_key(v)
+        x = T(inp["x"]).requires_grad_(True)
+        y = T(inp["y"]).requires_grad_(True)
+        xn = T(inp["xn"]).requires_grad_(True)
+        yn = T(inp["yn"]).requires_grad_(True)
+        kw = dict(x_lengths=T(inp["xl"], torch.int64), y_lengths=T(inp["yl"], torch.int64),
+                  batch_reduction=v["batch_reduction"], point_reduction=v["point_reduction"], norm=v["norm"],
+                  single_directional=v["single_directional"], abs_cosine=v["abs_cosine"])
+        if v["use_weights"]:
+            kw["weights"] = T(inp["w"])
+        if v["features"]:
+            kw.update(x_features={"normals": xn}, y_features={"normals": yn}, feature_names=["normals"])
+        loss, lf = chamfer_distance(x, y, **kw)
+        flat = []
+
+        def put(tag, t):
+            if isinstance(t, tuple):
+                for i, tt in enumerate(t):
+                    put(f"{tag}{i}", tt)
+            elif t is not None:
+                out[f"{key}/{tag}"] = t.detach().numpy()
+                flat.append(t)
+
+        put("loss", loss)
+        if lf is not None:
+            put("lossf", lf["normals"])
+        total = sum(t.sum() for t in flat)
+        total.backward()
+        out[f"{key}/grad_x"] = x.grad.numpy()
+        out[f"{key}/grad_y"] = y.grad.numpy()
+        if v["features"]:
+            out[f"{key}/grad_xn"] = xn.grad.numpy()
+            out[f"{key}/grad_yn"] = yn.grad.numpy()
+    # Pointclouds inputs (ragged lists + "normals" feature) must equal the tensor path
+    xl, yl = inp["xl"], inp["yl"]
+    pc_x = Pointclouds([T(inp["x"][n, : xl[n]]) for n in range(3)],
+                       features={"normals": [T(inp["xn"][n, : xl[n]]) for n in range(3)]})
+    pc_y = Pointclouds([T(inp["y"][n, : yl[n]]) for n in range(3)],
+                       features={"normals": [T(inp["yn"][n, : yl[n]]) for n in range(3)]})
+    loss, lf = chamfer_distance(pc_x, pc_y, feature_names=["normals"])
+    out["pointclouds/loss"] = loss.numpy()
+    out["pointclouds/lossf"] = lf["normals"].numpy()
+    save("chamfer", **out)
+
+
+def gen_big():
+    """cfg2-size single clouds: digests + sampled rows (the full idx would be 8 MB per cloud)."""
+    meta = {}
+    arrays = {}
+    for tag, seed1, seed2, P, K in (("cfg2_cloud", 7001, 7002, 65536, 16),):
+        p1 = cases.cloud(seed1, (1, P, 3))
+        p2 = cases.cloud(seed2, (1, P, 3))
+        L = torch.tensor([P], dtype=torch.int64)
+        idx, d = ref_C.knn_points_idx(T(p1), T(p2), L, L, 2, K, -1)
+        idx32 = idx.numpy().astype(np.int32)
+        meta[tag] = dict(seed1=seed1, seed2=seed2, P=P, K=K,
+                         idx_sha256=hashlib.sha256(idx32.tobytes()).hexdigest(),
+                         dists_sha256=hashlib.sha256(d.numpy().tobytes()).hexdigest())
+        rows = np.arange(0, P, 257)
+        arrays[tag + "/rows"] = rows
+        arrays[tag + "/idx_rows"] = idx32[0, rows]
+        arrays[tag + "/dists_rows"] = d.numpy()[0, rows]
+    # FPS at cfg3's per-cloud size
+    P, K = 131072, 1024
+    pts = cases.cloud(7003, (1, P, 3))
+    fi = ref_C.sample_farthest_points(T(pts), torch.tensor([P]), torch.tensor([K]), torch.tensor([0]))
+    arrays["cfg3_fps/idx"] = fi.numpy().astype(np.int32)
+    meta["cfg3_fps"] = dict(seed=7003, P=P, K=K)
+    # ball query at cfg3's per-cloud size, first 2048 queries
+    Q = 2048
+    bi, bd = ref_C.ball_query(T(pts[:, :Q]), T(pts), torch.tensor([Q]), torch.tensor([P]), 32, 0.2)
+    meta["cfg3_bq"] = dict(seed=7003, P=P, Q=Q, K=32, radius=0.2,
+                           idx_sha256=hashlib.sha256(bi.numpy().astype(np.int32).tobytes()).hexdigest(),
+                           dists_sha256=hashlib.sha256(bd.numpy().tobytes()).hexdigest())
+    arrays["cfg3_bq/idx_rows"] = bi.numpy().astype(np.int32)[0, ::64]
+    arrays["cfg3_bq/dists_rows"] = bd.numpy()[0, ::64]
+    save("big", **arrays)
+    with open(os.path.join(HERE, "big_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("wrote big_meta.json")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    gen_knn()
+    gen_knn_backward()
+    gen_ball_query()
+    gen_fps()
+    gen_packed()
+    gen_gather()
+    gen_chamfer()
+    if "--big" in sys.argv:
+        gen_big()

@@ -1,0 +1,137 @@
+"""CPU suite: the C-ABI library loads, exports every symbol include/pointops_amd.h
+declares, and the host-side mirror of the reference API validates arguments with
+the reference's error types/messages.  No compute calls (there is no GPU here and
+the product has no CPU fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "pointops_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(pointops_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+
+    from pytorch3d_pointops_amd import _C
+
+    lib = ctypes.CDLL(_C.LIB_PATH)
+    decl = declared_symbols()
+    assert len(decl) >= 14
+    for name in decl:
+        assert hasattr(lib, name), f"libpointops_amd.so lacks {name}"
+    assert sorted(_C.exported_symbols()) == decl  # the ctypes table binds exactly the header
+    assert lib.pointops_abi_version() == 1
+    lib.pointops_target_arch.restype = ctypes.c_char_p
+    assert lib.pointops_target_arch() == b"gfx950"
+
+
+def test_code_object_is_gfx950():
+    from pytorch3d_pointops_amd import _C
+
+    blob = open(_C.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_no_cpu_fallback():
+    from pytorch3d_pointops_amd.functions import knn_points, ball_query, sample_farthest_points, packed_to_padded
+
+    p = torch.rand(1, 8, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        knn_points(p, p, K=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ball_query(p, p, K=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sample_farthest_points(p, K=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        packed_to_padded(torch.rand(8, 3), torch.tensor([0, 4]), 4)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "pytorch3d_pointops_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, fn)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{fn} mentions the oracle"
+
+
+def test_knn_validation_errors():
+    from pytorch3d_pointops_amd.functions import knn_points, knn_gather
+
+    with pytest.raises(ValueError, match="same batch dimension"):
+        knn_points(torch.rand(2, 4, 3), torch.rand(3, 4, 3))
+    with pytest.raises(ValueError, match="same point dimension"):
+        knn_points(torch.rand(2, 4, 3), torch.rand(2, 4, 2))
+    with pytest.raises(ValueError, match="same batch dimension"):
+        knn_gather(torch.rand(2, 4, 3), torch.zeros(3, 4, 1, dtype=torch.int64))
+
+
+def test_ball_query_validation_errors():
+    from pytorch3d_pointops_amd.functions import ball_query
+
+    with pytest.raises(ValueError, match="same batch dimension"):
+        ball_query(torch.rand(2, 4, 3), torch.rand(3, 4, 3))
+    with pytest.raises(ValueError, match="same point dimension"):
+        ball_query(torch.rand(2, 4, 3), torch.rand(2, 4, 2))
+
+
+def test_fps_validation_errors():
+    from pytorch3d_pointops_amd.functions import sample_farthest_points
+
+    p = torch.rand(2, 10, 3)
+    with pytest.raises(ValueError, match="same batch dimension"):
+        sample_farthest_points(p, lengths=torch.tensor([10, 10, 10]))
+    with pytest.raises(ValueError, match="too large"):
+        sample_farthest_points(p, lengths=torch.tensor([10, 11]))
+    with pytest.raises(ValueError, match="K and points"):
+        sample_farthest_points(p, K=[1, 2, 3])
+
+
+def test_packed_validation_errors():
+    from pytorch3d_pointops_amd.functions.packed_to_padded import _PackedToPadded, _PaddedToPacked
+
+    f = torch.tensor([0, 2])
+    with pytest.raises(ValueError, match="2-dimensional"):
+        _PackedToPadded.apply(torch.rand(4), f, 2)
+    with pytest.raises(ValueError, match="1-dimensional"):
+        _PackedToPadded.apply(torch.rand(4, 3), f[None], 2)
+    with pytest.raises(ValueError, match="float32"):
+        _PackedToPadded.apply(torch.rand(4, 3).double(), f, 2)
+    with pytest.raises(ValueError, match="int64"):
+        _PackedToPadded.apply(torch.rand(4, 3), f.int(), 2)
+    with pytest.raises(ValueError, match="has to be int"):
+        _PackedToPadded.apply(torch.rand(4, 3), f, 2.0)
+    with pytest.raises(ValueError, match="3-dimensional"):
+        _PaddedToPacked.apply(torch.rand(4, 3), f, 4)
+
+
+def test_chamfer_validation_errors():
+    from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance
+
+    x = torch.rand(2, 5, 3)
+    with pytest.raises(ValueError, match="batch_reduction must be one of"):
+        chamfer_distance(x, x, batch_reduction="max")
+    with pytest.raises(ValueError, match="point_reduction must be one of"):
+        chamfer_distance(x, x, point_reduction="median")
+    with pytest.raises(ValueError, match="Batch reduction must be None"):
+        chamfer_distance(x, x, point_reduction=None)
+    with pytest.raises(ValueError, match="1 or 2 norm"):
+        chamfer_distance(x, x, norm=3)
+    with pytest.raises(ValueError, match='Features must be None if point_reduction is "max"'):
+        chamfer_distance(x, x, point_reduction="max", feature_names=["normals"])
+    with pytest.raises(ValueError, match="shape \\(N, P, D\\)"):
+        chamfer_distance(torch.rand(5, 3), x)
+    with pytest.raises(ValueError, match="shape \\(N,\\)"):
+        chamfer_distance(x, x, x_lengths=torch.tensor([5]))
+    with pytest.raises(ValueError, match="too long"):
+        chamfer_distance(x, x, x_lengths=torch.tensor([5, 6]))
+    with pytest.raises(ValueError, match="should be either"):
+        chamfer_distance([1, 2], x)

@@ -1,0 +1,406 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the
+public functions.* API -> ctypes -> C ABI, against (a) the golden vectors the
+reference itself produced and (b) the CPU oracle on the same seeded inputs.
+
+Bars: idx outputs bit-exact; fp32 distance outputs bit-exact where the arithmetic is
+order-free (knn / ball query dists, grad_p1, gathers, copies), 1e-5 where fp32 atomics
+or tree reductions reorder sums (grad_p2, chamfer losses).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import GOLDEN, bits, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star tolerance for fp32 dists / chamfer
+
+
+def G(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t if dtype is None else t.to(dtype)
+
+
+def close(a, b, tol=TOL):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    return a.shape == b.shape and (a.size == 0 or float(np.abs(a - b).max()) <= tol * scale)
+
+
+def test_native_library_is_loaded(dev):
+    from pytorch3d_pointops_amd import _C
+
+    maps = open("/proc/self/maps").read()
+    assert "libpointops_amd.so" in maps
+    # exactly one HIP runtime in the process (ours must bind to the one torch loaded)
+    hips = {line.split()[-1] for line in maps.splitlines() if "libamdhip64" in line}
+    assert len(hips) == 1, hips
+    assert _C.knn_check_version(3, 3, 16)
+
+
+# ------------------------------------------------------------------ KNN
+@pytest.mark.parametrize("name", sorted(cases.knn_cases()))
+def test_knn_points(dev, oracle, name):
+    from pytorch3d_pointops_amd.functions import knn_points
+
+    g = load_golden("knn")
+    c = cases.knn_cases()[name]
+    r = knn_points(G(c["p1"], dev), G(c["p2"], dev), G(c["l1"], dev), G(c["l2"], dev), norm=c["norm"], K=c["K"],
+                   return_nn=True)
+    idx = r.idx.cpu().numpy()
+    d = r.dists.cpu().numpy()
+    assert np.array_equal(idx, g[name + "/idx"].astype(np.int64)), "idx differs from the reference golden"
+    assert np.array_equal(bits(d), bits(g[name + "/dists"])), "dists differ from the reference golden"
+    assert np.array_equal(r.knn.cpu().numpy(), g[name + "/knn"])
+    oi, od = oracle.knn_points_idx(c["p1"], c["p2"], c["l1"], c["l2"], c["norm"], c["K"])
+    assert np.array_equal(idx, oi) and np.array_equal(bits(d), bits(od))
+
+
+@pytest.mark.parametrize("version", [-1, 0, 1, 2, 3])
+def test_knn_versions_agree(dev, oracle, version):
+    """`version` never changes results (reference: functions/knn.py:121, knn.cu:351-365)."""
+    from pytorch3d_pointops_amd.functions import knn_points
+
+    c = cases.knn_cases()["ties_lattice_k16"]
+    r = knn_points(G(c["p1"], dev), G(c["p2"], dev), G(c["l1"], dev), G(c["l2"], dev), K=c["K"], version=version)
+    oi, od = oracle.knn_points_idx(c["p1"], c["p2"], c["l1"], c["l2"], 2, c["K"])
+    assert np.array_equal(r.idx.cpu().numpy(), oi)
+    assert np.array_equal(bits(r.dists.cpu().numpy()), bits(od))
+
+
+def test_knn_default_lengths_and_empty(dev, oracle):
+    from pytorch3d_pointops_amd.functions import knn_points
+
+    p1 = cases.cloud(901, (2, 77, 3))
+    p2 = cases.cloud(902, (2, 301, 3))
+    r = knn_points(G(p1, dev), G(p2, dev), K=7)
+    oi, od = oracle.knn_points_idx(p1, p2, np.array([77, 77]), np.array([301, 301]), 2, 7)
+    assert np.array_equal(r.idx.cpu().numpy(), oi) and np.array_equal(bits(r.dists.cpu().numpy()), bits(od))
+    assert r.knn is None
+    # P1 == 0 works and returns (N,0,K)
+    e = knn_points(torch.zeros(2, 0, 3, device=dev), G(p2, dev), K=3)
+    assert tuple(e.idx.shape) == (2, 0, 3) and tuple(e.dists.shape) == (2, 0, 3)
+    with pytest.raises(ValueError, match="1 or 2 norm"):
+        knn_points(G(p1, dev), G(p2, dev), norm=3)
+    # non-contiguous inputs are made contiguous (functions/knn.py:178-179)
+    pt = G(np.ascontiguousarray(p1.transpose(0, 2, 1)), dev).transpose(1, 2)
+    r2 = knn_points(pt, G(p2, dev), K=7)
+    assert torch.equal(r2.idx, r.idx)
+
+
+@pytest.mark.parametrize("name", sorted(cases.knn_backward_cases()))
+def test_knn_backward(dev, oracle, name):
+    from pytorch3d_pointops_amd.functions import knn_points
+
+    g = load_golden("knn_backward")
+    c = cases.knn_backward_cases()[name]
+    p1 = G(c["p1"], dev).requires_grad_(True)
+    p2 = G(c["p2"], dev).requires_grad_(True)
+    r = knn_points(p1, p2, G(c["l1"], dev), G(c["l2"], dev), norm=c["norm"], K=c["K"])
+    assert not r.idx.requires_grad
+    grad = cases.grad_for(name, tuple(r.dists.shape))
+    r.dists.backward(G(grad, dev))
+    g1 = p1.grad.cpu().numpy()
+    g2 = p2.grad.cpu().numpy()
+    # grad_p1: per-query register sum in k order == CPU order -> bit-exact
+    assert np.array_equal(bits(g1), bits(g[name + "/grad_p1"]))
+    # grad_p2: fp32 atomics, order-dependent last bits
+    assert close(g2, g[name + "/grad_p2"])
+    o1, o2 = oracle.knn_points_backward(c["p1"], c["p2"], c["l1"], c["l2"], r.idx.cpu().numpy(), c["norm"], grad)
+    assert np.array_equal(bits(g1), bits(o1)) and close(g2, o2)
+
+
+# ------------------------------------------------------------------ gather
+def test_knn_gather_and_masked_gather(dev):
+    from pytorch3d_pointops_amd.functions import knn_gather, masked_gather
+    from pytorch3d_pointops_amd import synth
+
+    g = load_golden("gather")
+    x = cases.cloud(601, (2, 50, 5))
+    idx = synth.randint(602, 0, 49, (2, 30, 4))
+    lengths = np.array([50, 2])
+    xr = G(x, dev).requires_grad_(True)
+    o = knn_gather(xr, G(idx, dev), G(lengths, dev))
+    assert np.array_equal(o.detach().cpu().numpy(), g["knn_gather/out"])
+    up = cases.grad_for("kg", tuple(o.shape))
+    (o * G(up, dev)).sum().backward()
+    assert close(xr.grad.cpu().numpy(), g["knn_gather/grad_x"])
+    midx = idx.copy()
+    midx[0, ::3, 1] = -1
+    midx[1, :, 3] = -1
+    xr2 = G(x, dev).requires_grad_(True)
+    o2 = masked_gather(xr2, G(midx, dev))
+    assert np.array_equal(o2.detach().cpu().numpy(), g["masked_gather3/out"])
+    (o2 * G(up, dev)).sum().backward()
+    assert close(xr2.grad.cpu().numpy(), g["masked_gather3/grad_x"])
+    o3 = masked_gather(G(x, dev), G(np.ascontiguousarray(midx[:, :, 1]), dev))
+    assert np.array_equal(o3.cpu().numpy(), g["masked_gather2/out"])
+    with pytest.raises(ValueError, match="not supported"):
+        masked_gather(G(x, dev), G(midx, dev)[..., None])
+
+
+# ------------------------------------------------------------------ ball query
+@pytest.mark.parametrize("name", sorted(cases.ball_query_cases()))
+def test_ball_query(dev, oracle, name):
+    from pytorch3d_pointops_amd.functions import ball_query
+
+    g = load_golden("ball_query")
+    c = cases.ball_query_cases()[name]
+    p1 = G(c["p1"], dev).requires_grad_(True)
+    p2 = G(c["p2"], dev).requires_grad_(True)
+    r = ball_query(p1, p2, G(c["l1"], dev), G(c["l2"], dev), K=c["K"], radius=c["radius"], return_nn=True)
+    idx = r.idx.cpu().numpy()
+    d = r.dists.detach().cpu().numpy()
+    assert np.array_equal(idx, g[name + "/idx"].astype(np.int64))
+    assert np.array_equal(bits(d), bits(g[name + "/dists"]))
+    assert np.array_equal(r.knn.detach().cpu().numpy(), g[name + "/knn"])
+    oi, od = oracle.ball_query(c["p1"], c["p2"], c["l1"], c["l2"], c["K"], c["radius"])
+    assert np.array_equal(idx, oi) and np.array_equal(bits(d), bits(od))
+    assert (d[idx >= 0] < np.float32(c["radius"]) ** 2).all()  # the reference example's own check
+    up = cases.grad_for("bq" + name, tuple(d.shape))
+    (r.dists * G(up, dev)).sum().backward()
+    assert np.array_equal(bits(p1.grad.cpu().numpy()), bits(g[name + "/grad_p1"]))
+    assert close(p2.grad.cpu().numpy(), g[name + "/grad_p2"])
+
+
+# ------------------------------------------------------------------ FPS
+@pytest.mark.parametrize("name", sorted(cases.fps_cases()))
+def test_sample_farthest_points(dev, oracle, name):
+    from pytorch3d_pointops_amd import _C
+    from pytorch3d_pointops_amd.functions import masked_gather, sample_farthest_points
+    from pytorch3d_pointops_amd.functions.sample_farthest_points import sample_farthest_points_naive
+
+    g = load_golden("fps")
+    c = cases.fps_cases()[name]
+    pts = G(c["points"], dev)
+    idx = _C.sample_farthest_points(pts, G(c["lengths"], dev), G(c["K"], dev), G(c["start"], dev))
+    got = idx.cpu().numpy()
+    assert np.array_equal(got, g[name + "/idx"].astype(np.int64))
+    assert np.array_equal(got, oracle.sample_farthest_points(c["points"], c["lengths"], c["K"], c["start"]))
+    assert np.array_equal(masked_gather(pts, idx).cpu().numpy(), g[name + "/points"])
+    if (c["start"] == 0).all():
+        sp, si = sample_farthest_points(pts, G(c["lengths"], dev), G(c["K"], dev))
+        assert torch.equal(si, idx)
+        assert np.array_equal(sp.cpu().numpy(), g[name + "/points"])
+        if name not in ("all_equal", "big_cloud"):
+            _, ni = sample_farthest_points_naive(pts, G(c["lengths"], dev), G(c["K"], dev))
+            assert torch.equal(ni, idx)  # examples/fps_on_pointclouds.py:153
+
+
+def test_fps_int_and_list_K_and_random_start(dev):
+    from pytorch3d_pointops_amd.functions import sample_farthest_points
+
+    pts = G(cases.cloud(301, (4, 500, 3)), dev)
+    a, ai = sample_farthest_points(pts, K=32)
+    g = load_golden("fps")
+    assert np.array_equal(ai.cpu().numpy(), g["fixed_k/idx"].astype(np.int64))
+    b, bi = sample_farthest_points(pts, lengths=G(np.array([500, 120, 33, 1]), dev), K=[10, 200, 5, 3])
+    assert np.array_equal(bi.cpu().numpy(), g["per_cloud_k/idx"].astype(np.int64))
+    torch.manual_seed(0)
+    c, ci = sample_farthest_points(pts, K=8, random_start_point=True)
+    assert tuple(ci.shape) == (4, 8) and (ci >= 0).all()
+    # differentiable w.r.t. points through the gather
+    pr = pts.clone().requires_grad_(True)
+    sp, _ = sample_farthest_points(pr, K=4)
+    sp.sum().backward()
+    assert float(pr.grad.sum()) == 4 * 4 * 3
+
+
+# ------------------------------------------------------------------ packed <-> padded
+@pytest.mark.parametrize("name", sorted(cases.packed_cases()))
+def test_packed_padded(dev, name):
+    from pytorch3d_pointops_amd.functions import packed_to_padded, padded_to_packed
+
+    g = load_golden("packed_padded")
+    c = cases.packed_cases()[name]
+    x, first, F = cases.packed_inputs(c)
+    xt = G(x, dev).requires_grad_(True)
+    arg = xt[:, 0] if c["D"] == 1 else xt
+    padded = packed_to_padded(arg, G(first, dev), int(c["max_size"]))
+    assert np.array_equal(padded.detach().cpu().numpy(), g[name + "/padded"])
+    up = cases.grad_for("pp" + name, tuple(padded.shape))
+    (padded * G(up, dev)).sum().backward()
+    assert np.array_equal(xt.grad.cpu().numpy(), g[name + "/grad_packed"])
+    back = padded_to_packed(padded.detach(), G(first, dev), F)
+    assert np.array_equal(back.cpu().numpy(), g[name + "/roundtrip"])
+    assert np.array_equal(back.cpu().numpy().reshape(x.shape if c["D"] > 1 else (F,)), x if c["D"] > 1 else x[:, 0])
+    pt = G(cases.grad_for("pq" + name, tuple(padded.shape)), dev).requires_grad_(True)
+    pk = padded_to_packed(pt, G(first, dev), F)
+    assert np.array_equal(pk.detach().cpu().numpy(), g[name + "/packed_of_g"])
+    pk.sum().backward()
+    assert np.array_equal(pt.grad.cpu().numpy(), g[name + "/grad_padded_ones"])
+
+
+def test_packed_padded_trailing_dims(dev):
+    from pytorch3d_pointops_amd.functions import packed_to_padded, padded_to_packed
+
+    g = load_golden("packed_padded")
+    x = cases.cloud(410, (15, 2, 3))
+    first = np.array([0, 5, 5, 12], np.int64)
+    p3 = packed_to_padded(G(x, dev), G(first, dev), 7)
+    assert np.array_equal(p3.cpu().numpy(), g["trailing/padded"])
+    assert np.array_equal(padded_to_packed(p3, G(first, dev), 15).cpu().numpy(), g["trailing/roundtrip"])
+    # max_size_dim != 1
+    q = p3.movedim(1, 2).contiguous()
+    assert np.array_equal(padded_to_packed(q, G(first, dev), 15, max_size_dim=2).cpu().numpy(), g["trailing/roundtrip"])
+
+
+# ------------------------------------------------------------------ chamfer
+def _chamfer_call(dev, inp, v, as_leaf=True):
+    from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance
+
+    x = G(inp["x"], dev).requires_grad_(as_leaf)
+    y = G(inp["y"], dev).requires_grad_(as_leaf)
+    xn = G(inp["xn"], dev).requires_grad_(as_leaf)
+    yn = G(inp["yn"], dev).requires_grad_(as_leaf)
+    kw = dict(x_lengths=G(inp["xl"], dev), y_lengths=G(inp["yl"], dev), batch_reduction=v["batch_reduction"],
+              point_reduction=v["point_reduction"], norm=v["norm"], single_directional=v["single_directional"],
+              abs_cosine=v["abs_cosine"])
+    if v["use_weights"]:
+        kw["weights"] = G(inp["w"], dev)
+    if v["features"]:
+        kw.update(x_features={"normals": xn}, y_features={"normals": yn}, feature_names=["normals"])
+    loss, lf = chamfer_distance(x, y, **kw)
+    return x, y, xn, yn, loss, lf
+
+
+@pytest.mark.parametrize("v", cases.chamfer_variants(), ids=cases.variant_key)
+def test_chamfer_distance(dev, v):
+    g = load_golden("chamfer")
+    key = cases.variant_key(v)
+    inp = cases.chamfer_inputs()
+    x, y, xn, yn, loss, lf = _chamfer_call(dev, inp, v)
+    flat = []
+
+    def chk(tag, t):
+        if isinstance(t, tuple):
+            for i, tt in enumerate(t):
+                chk(f"{tag}{i}", tt)
+        elif t is not None:
+            want = g[f"{key}/{tag}"]
+            assert close(t.detach().cpu().numpy(), want), (key, tag)
+            flat.append(t)
+
+    chk("loss", loss)
+    if v["features"]:
+        assert lf is not None
+        chk("lossf", lf["normals"])
+    else:
+        assert lf is None
+    sum(t.sum() for t in flat).backward()
+    assert close(x.grad.cpu().numpy(), g[f"{key}/grad_x"]), key
+    assert close(y.grad.cpu().numpy(), g[f"{key}/grad_y"]), key
+    if v["features"]:
+        assert close(xn.grad.cpu().numpy(), g[f"{key}/grad_xn"]), key
+        assert close(yn.grad.cpu().numpy(), g[f"{key}/grad_yn"]), key
+
+
+def test_chamfer_pointclouds_input(dev):
+    from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance
+    from pytorch3d_pointops_amd.structures import Pointclouds
+
+    g = load_golden("chamfer")
+    inp = cases.chamfer_inputs()
+    xl, yl = inp["xl"], inp["yl"]
+    pc_x = Pointclouds([G(inp["x"][n, : xl[n]], dev) for n in range(3)],
+                       features={"normals": [G(inp["xn"][n, : xl[n]], dev) for n in range(3)]})
+    pc_y = Pointclouds([G(inp["y"][n, : yl[n]], dev) for n in range(3)],
+                       features={"normals": [G(inp["yn"][n, : yl[n]], dev) for n in range(3)]})
+    loss, lf = chamfer_distance(pc_x, pc_y, feature_names=["normals"])
+    assert close(loss.cpu().numpy(), g["pointclouds/loss"])
+    assert close(lf["normals"].cpu().numpy(), g["pointclouds/lossf"])
+
+
+def test_chamfer_zero_weights_and_errors(dev):
+    from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance
+
+    x = G(cases.cloud(950, (2, 20, 3)), dev).requires_grad_(True)
+    y = G(cases.cloud(951, (2, 30, 3)), dev)
+    loss, lf = chamfer_distance(x, y, weights=torch.zeros(2, device=dev))
+    assert float(loss) == 0.0 and lf is None
+    loss.backward()
+    assert float(x.grad.abs().sum()) == 0.0
+    with pytest.raises(ValueError, match="cannot be negative"):
+        chamfer_distance(x, y, weights=torch.tensor([1.0, -1.0], device=dev))
+    with pytest.raises(ValueError, match="shape \\(N,\\)"):
+        chamfer_distance(x, y, weights=torch.ones(3, device=dev))
+
+
+# ------------------------------------------------------------------ full-size properties / digests
+def test_cfg2_cloud_digest(dev):
+    """One cfg2-size cloud (N=M=65536, K=16): sha256 of idx and dists equal the reference run."""
+    from pytorch3d_pointops_amd.functions import knn_points
+
+    meta = json.load(open(os.path.join(GOLDEN, "big_meta.json")))["cfg2_cloud"]
+    P, K = meta["P"], meta["K"]
+    p1 = cases.cloud(meta["seed1"], (1, P, 3))
+    p2 = cases.cloud(meta["seed2"], (1, P, 3))
+    r = knn_points(G(p1, dev), G(p2, dev), K=K)
+    idx32 = r.idx.cpu().numpy().astype(np.int32)
+    assert hashlib.sha256(idx32.tobytes()).hexdigest() == meta["idx_sha256"]
+    assert hashlib.sha256(r.dists.cpu().numpy().tobytes()).hexdigest() == meta["dists_sha256"]
+
+
+def test_cfg2_full_batch_properties(dev):
+    """BASELINE.json configs[1] at full size (B=32, N=M=65536, K=16): size-independent properties.
+    sortedness, index range, distances recomputed from idx bit-exactly, batch independence
+    (cloud b of the batched call == the single-cloud call whose digest is pinned above)."""
+    from pytorch3d_pointops_amd.functions import knn_points
+
+    meta = json.load(open(os.path.join(GOLDEN, "big_meta.json")))["cfg2_cloud"]
+    B, P, K = 32, meta["P"], meta["K"]
+    p1 = np.empty((B, P, 3), np.float32)
+    p2 = np.empty((B, P, 3), np.float32)
+    for b in range(B):
+        p1[b] = cases.cloud(meta["seed1"] + 10 * b, (P, 3))
+        p2[b] = cases.cloud(meta["seed2"] + 10 * b, (P, 3))
+    a, bq = G(p1, dev), G(p2, dev)
+    r = knn_points(a, bq, K=K)
+    d, idx = r.dists, r.idx
+    assert bool((d[..., 1:] >= d[..., :-1]).all())
+    assert bool(((idx >= 0) & (idx < P)).all())
+    # ties ordered by index
+    tie = d[..., 1:] == d[..., :-1]
+    assert bool((idx[..., 1:][tie] > idx[..., :-1][tie]).all())
+    # distances recomputed from the returned indices, unfused fp32, must be bit-equal
+    nb = torch.gather(bq, 1, idx.reshape(B, P * K, 1).expand(-1, -1, 3)).reshape(B, P, K, 3)
+    diff = a[:, :, None, :] - nb
+    sq = diff * diff
+    re = (sq[..., 0] + sq[..., 1]) + sq[..., 2]
+    assert torch.equal(re, d)
+    # cloud 0 equals the pinned single-cloud digest
+    idx32 = idx[0:1].cpu().numpy().astype(np.int32)
+    assert hashlib.sha256(idx32.tobytes()).hexdigest() == meta["idx_sha256"]
+    # K-th distance is a true bound: count of points strictly closer than the K-th equals at most K-1
+    # (checked on a sample of queries against a brute-force torch distance matrix)
+    qs = torch.arange(0, P, 4099, device=dev)
+    for b in (0, B - 1):
+        dq = a[b, qs][:, None, :] - bq[b][None, :, :]
+        dq = dq * dq
+        full = (dq[..., 0] + dq[..., 1]) + dq[..., 2]
+        kth = d[b, qs, K - 1]
+        assert bool(((full < kth[:, None]).sum(1) <= K - 1).all())
+        assert bool(((full <= kth[:, None]).sum(1) >= K).all())
+
+
+def test_cfg3_fps_and_ball_query_full_cloud(dev):
+    from pytorch3d_pointops_amd import _C
+
+    meta = json.load(open(os.path.join(GOLDEN, "big_meta.json")))
+    g = load_golden("big")
+    m = meta["cfg3_fps"]
+    pts = G(cases.cloud(m["seed"], (1, m["P"], 3)), dev)
+    one = lambda v: torch.tensor([v], dtype=torch.int64, device=dev)
+    idx = _C.sample_farthest_points(pts, one(m["P"]), one(m["K"]), one(0))
+    assert np.array_equal(idx.cpu().numpy(), g["cfg3_fps/idx"].astype(np.int64))
+    b = meta["cfg3_bq"]
+    bi, bd = _C.ball_query(pts[:, : b["Q"]].contiguous(), pts, one(b["Q"]), one(b["P"]), b["K"], b["radius"])
+    assert hashlib.sha256(bi.cpu().numpy().astype(np.int32).tobytes()).hexdigest() == b["idx_sha256"]
+    assert hashlib.sha256(bd.cpu().numpy().tobytes()).hexdigest() == b["dists_sha256"]
