@@ -142,8 +142,16 @@ def _chamfer_distance_single_direction(
         if not (weights >= 0).all():
             raise ValueError("weights cannot be negative.")
         if weights.sum() == 0.0:
-            weights = weights.view(N, 1)
-            return ((x.sum((1, 2)) * weights) * 0.0, (x.sum((1, 2)) * weights) * 0.0)
+            # All-zero weights: a zero loss that stays attached to x's graph.  The reference's
+            # early return (functions/chamfer.py:128-130) hands back a TENSOR where its caller
+            # expects the per-feature dict and raises IndexError for every reduction mode
+            # (verified against the compiled reference); upstream PyTorch3D's intent -- zeros --
+            # is what is implemented here ("Deviations").
+            zero = (x.sum((1, 2)) * weights) * 0.0  # (N,)
+            if point_reduction is None:
+                zero = zero[:, None].expand(N, P1)
+            zf = {name: zero for name in feature_names} if return_features else None
+            return zero, zf
 
     x_nn = knn_points(x, y, lengths1=x_lengths, lengths2=y_lengths, norm=norm, K=1)
     cham_x = x_nn.dists[..., 0]  # (N, P1); rows >= x_lengths are already 0 (kernel padding)
