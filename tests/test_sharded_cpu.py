@@ -1,0 +1,127 @@
+"""world_size-2 gloo tests (CPU) of the batch-sharding layer: partitioning, the
+differentiable all_gather of per-cloud losses, and the sharded batch reduction equal to
+the single-process reduction.  The local per-cloud computation is injected (an oracle-based
+numpy chamfer) because the product path has no CPU implementation."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_and_balanced_assignment():
+    from pytorch3d_pointops_amd.sharded import balanced_assignment, shard_bounds
+
+    assert shard_bounds(256, 8) == [(32 * r, 32 * r + 32) for r in range(8)]
+    assert shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard_bounds(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    costs = [9, 1, 8, 2, 7, 3, 6, 4]
+    bins = balanced_assignment(costs, 2)
+    assert sorted(sum(bins, [])) == list(range(8))
+    loads = [sum(costs[i] for i in b) for b in bins]
+    assert abs(loads[0] - loads[1]) <= 2
+
+
+def _oracle_chamfer_per_cloud(x, y, xl, yl, w):
+    """per-cloud bidirectional mean chamfer via the CPU oracle (torch tensors in/out, with a
+    hand-written gradient so autograd flows through the all_gather)."""
+    from oracle.oracle import Oracle
+
+    ora = Oracle()
+
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, y):
+            xn, yn = x.detach().numpy(), y.detach().numpy()
+            i1, d1 = ora.knn_points_idx(xn, yn, xl, yl, 2, 1)
+            i2, d2 = ora.knn_points_idx(yn, xn, yl, xl, 2, 1)
+            ctx.save = (xn, yn, i1, i2)
+            a = torch.from_numpy(d1[..., 0].sum(1) / np.maximum(xl, 1)).float()
+            b = torch.from_numpy(d2[..., 0].sum(1) / np.maximum(yl, 1)).float()
+            return (a + b) * w
+
+        @staticmethod
+        def backward(ctx, g):
+            xn, yn, i1, i2 = ctx.save
+            gn = (g * w).numpy()
+            g1 = (gn / np.maximum(xl, 1))[:, None, None] * np.ones_like(i1, np.float32)
+            g2 = (gn / np.maximum(yl, 1))[:, None, None] * np.ones_like(i2, np.float32)
+            ax, ay = ora.knn_points_backward(xn, yn, xl, yl, i1, 2, g1.astype(np.float32))
+            by, bx = ora.knn_points_backward(yn, xn, yl, xl, i2, 2, g2.astype(np.float32))
+            return torch.from_numpy(ax + bx), torch.from_numpy(ay + by)
+
+    return F.apply(x, y)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pytorch3d_pointops_amd.sharded import all_gather_losses, shard_bounds, sharded_chamfer_distance
+
+        B = 5  # uneven split: 3 + 2
+        x = cases.cloud(1201, (B, 40, 3))
+        y = cases.cloud(1202, (B, 55, 3))
+        xl = np.array([40, 17, 33, 40, 5])
+        yl = np.array([55, 55, 9, 21, 30])
+        w = np.array([1.0, 0.5, 2.0, 1.5, 0.25], np.float32)
+        s, e = shard_bounds(B, world)[rank]
+        xt = torch.from_numpy(x[s:e]).requires_grad_(True)
+        yt = torch.from_numpy(y[s:e]).requires_grad_(True)
+
+        def local_fn(xx, yy, weights=None, **kw):
+            return _oracle_chamfer_per_cloud(xx, yy, xl[s:e], yl[s:e], weights), None
+
+        loss, lf = sharded_chamfer_distance(xt, yt, B, weights_local=torch.from_numpy(w[s:e]),
+                                            batch_reduction="mean", local_fn=local_fn)
+        loss.backward()
+        # raw gather with uneven counts
+        vec = all_gather_losses(torch.arange(s, e, dtype=torch.float32), [3, 2])
+        q.put((rank, float(loss), xt.grad.numpy().copy(), yt.grad.numpy().copy(), vec.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_chamfer_matches_single_process_gloo():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=240)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process expectation on the full batch
+    B = 5
+    x = cases.cloud(1201, (B, 40, 3))
+    y = cases.cloud(1202, (B, 55, 3))
+    xl = np.array([40, 17, 33, 40, 5])
+    yl = np.array([55, 55, 9, 21, 30])
+    w = np.array([1.0, 0.5, 2.0, 1.5, 0.25], np.float32)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    yt = torch.from_numpy(y).requires_grad_(True)
+    per = _oracle_chamfer_per_cloud(xt, yt, xl, yl, torch.from_numpy(w))
+    full = per.sum() / float(w.sum())
+    full.backward()
+    assert abs(res[0][0] - float(full)) <= 1e-6 and res[0][0] == res[1][0]  # identical on every rank
+    gx = np.concatenate([res[0][1], res[1][1]])
+    gy = np.concatenate([res[0][2], res[1][2]])
+    assert np.allclose(gx, xt.grad.numpy(), atol=1e-7) and np.allclose(gy, yt.grad.numpy(), atol=1e-7)
+    assert np.array_equal(res[0][3], np.arange(5, dtype=np.float32))
+    assert np.array_equal(res[1][3], np.arange(5, dtype=np.float32))
