@@ -63,6 +63,16 @@ int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* len
                             float* dists, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/*
+ * Diagnostics for the grid-pruned KNN family (version 3): after a pointops_knn_points_idx
+ * call that used `workspace`, copies the per-cloud number of queries that the pruning
+ * bound could not certify (and that were answered by the whole-cloud scan instead) into
+ * counts (2,N) int32 on the device: row 0 = queries re-searched wave-per-query on a growing
+ * cell cube, row 1 = queries that ended in the whole-cloud scan.  Stream-ordered, no sync.
+ */
+int pointops_knn_grid_fallback_counts(const void* workspace, int64_t N, int64_t P1, int64_t P2,
+                                      int64_t K, int32_t* counts, void* stream);
+
 /* Replaces `_C.knn_check_version` (reference: csrc/knn/knn.h:161, knn.cu:292-303). */
 int pointops_knn_check_version(int version, int64_t D, int64_t K);
 

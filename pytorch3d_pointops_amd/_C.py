@@ -32,6 +32,7 @@ _SIGNATURES = {
     "pointops_knn_points_idx": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _i64, _int,
                                        _vp, _vp, _vp, _sz, _vp]),
     "pointops_knn_check_version": (_int, [_int, _i64, _i64]),
+    "pointops_knn_grid_fallback_counts": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "pointops_knn_points_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                             _i64, _int, _vp, _vp, _vp]),
     "pointops_ball_query": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _vp, _vp,
@@ -128,6 +129,31 @@ def knn_points_idx(p1, p2, lengths1, lengths2, norm: int, K: int, version: int =
             "knn_points_idx",
         )
     return idxs, dists
+
+
+def knn_grid_fallback_counts(p1, p2, lengths1, lengths2, norm: int, K: int):
+    """Diagnostics: run the grid family (version 3) and return (idx, dists, counts) where
+    counts[0, n] = queries of cloud n re-searched wave-per-query on a growing cell cube,
+    counts[1, n] = queries that ended in the whole-cloud scan."""
+    dev = _require_gpu(p1, p2, lengths1, lengths2)
+    p1, p2 = p1.contiguous(), p2.contiguous()
+    N, P1, D = p1.shape
+    P2 = p2.shape[1]
+    if not knn_check_version(3, D, K):
+        raise RuntimeError("grid family needs D <= 3 and K <= 32")
+    with torch.cuda.device(dev):
+        idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
+        dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
+        ws_bytes = _lib.pointops_knn_workspace_bytes(N, P1, P2, D, K, 3)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        counts = torch.zeros((2, N), dtype=torch.int32, device=dev)
+        _check(_lib.pointops_knn_points_idx(p1.data_ptr(), p2.data_ptr(), lengths1.data_ptr(),
+                                            lengths2.data_ptr(), N, P1, P2, D, int(norm), int(K), 3,
+                                            idxs.data_ptr(), dists.data_ptr(), ws.data_ptr(), ws_bytes,
+                                            _stream()), "knn_points_idx")
+        _check(_lib.pointops_knn_grid_fallback_counts(ws.data_ptr(), N, P1, P2, int(K), counts.data_ptr(),
+                                                      _stream()), "knn_grid_fallback_counts")
+    return idxs, dists, counts
 
 
 def knn_check_version(version: int, D: int, K: int) -> bool:

@@ -23,123 +23,52 @@
 //   * grid = clouds x ceil(P1/256) workgroups of 256 lanes (>> 256 CUs at the
 //     bench sizes); all workgroups of a cloud re-stream the same 12*P2 bytes,
 //     which stay L2/Infinity-Cache resident (786 KB per cloud at P2=65536).
-#include "common.h"
+#include "knn_common.h"
+#include "knn_grid.h"
 
 namespace pointops {
 
 // ---------------------------------------------------------------------------
-// distance helpers (unfused; see common.h)
+// Register kernel: D in [1,8], K <= KC <= 32.  One lane per query, whole-cloud scan.
+// With `qlist` != nullptr the lanes of workgroup (n, tile) take their queries from
+// qlist[n*P1 + tile*256 + lane] for lane < qcount[n] (the exact fallback pass of the
+// grid search, knn_grid.hip); otherwise lane = query row and padded rows are zeroed.
 // ---------------------------------------------------------------------------
-template <int D, int NORM>
-__device__ __forceinline__ float pair_dist(const float (&a)[D], const float* __restrict__ b) {
-  float acc;
-  {
-    const float diff = a[0] - b[0];
-    acc = (NORM == 1) ? __builtin_fabsf(diff) : diff * diff;
-  }
-#pragma unroll
-  for (int d = 1; d < D; ++d) {
-    const float diff = a[d] - b[d];
-    acc = (NORM == 1) ? (acc + __builtin_fabsf(diff)) : (acc + diff * diff);
-  }
-  return acc;
-}
-
-// Sorted (ascending) register top-K.  insert() requires d < dk[KC-1].
-template <int KC>
-struct TopK {
-  float dk[KC];
-  int ik[KC];
-  __device__ __forceinline__ void init() {
-#pragma unroll
-    for (int i = 0; i < KC; ++i) {
-      dk[i] = __builtin_inff();
-      ik[i] = 0;
-    }
-  }
-  __device__ __forceinline__ float worst() const { return dk[KC - 1]; }
-  __device__ __forceinline__ void insert(float d, int j) {
-#pragma unroll
-    for (int i = KC - 1; i > 0; --i) {
-      const bool up = d < dk[i - 1];  // element i-1 moves up to slot i
-      const bool here = d < dk[i];    // newcomer lands at or below slot i
-      dk[i] = up ? dk[i - 1] : (here ? d : dk[i]);
-      ik[i] = up ? ik[i - 1] : (here ? j : ik[i]);
-    }
-    if (d < dk[0]) {
-      dk[0] = d;
-      ik[0] = j;
-    }
-  }
-};
-
-// ---------------------------------------------------------------------------
-// Register kernel: D in [1,8], K <= KC <= 32.
-// ---------------------------------------------------------------------------
-constexpr int kKnnBlock = 256;
-constexpr int kTileP2 = 8;  // p2 points fetched per scalar-load group
-
 template <int D, int KC, int NORM>
 __global__ __launch_bounds__(kKnnBlock) void knn_reg_kernel(
     const float* __restrict__ p1, const float* __restrict__ p2,
     const int64_t* __restrict__ lengths1, const int64_t* __restrict__ lengths2, int P1, int P2,
-    int K, int tiles_per_cloud, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+    int K, int tiles_per_cloud, const int* __restrict__ qlist, const int* __restrict__ qcount,
+    int64_t* __restrict__ idxs, float* __restrict__ dists) {
   const int n = blockIdx.x / tiles_per_cloud;  // wave-uniform
   const int tile = blockIdx.x - n * tiles_per_cloud;
-  const int i = tile * kKnnBlock + threadIdx.x;
-  if (i >= P1) return;
-  const int len1 = (int)lengths1[n];
+  int i = tile * kKnnBlock + threadIdx.x;
   int len2 = (int)lengths2[n];
   if (len2 > P2) len2 = P2;
   if (len2 < 0) len2 = 0;
-  const int64_t row = (int64_t)n * P1 + i;
-  int64_t* __restrict__ orow_i = idxs + row * K;
-  float* __restrict__ orow_d = dists + row * K;
-
-  if (i >= len1) {  // padded query row: zeros (knn_cpu.cpp:25-26)
-    for (int k = 0; k < K; ++k) {
-      orow_i[k] = 0;
-      orow_d[k] = 0.0f;
+  if (qlist != nullptr) {
+    if (i >= qcount[n]) return;
+    i = qlist[(int64_t)n * P1 + i];
+  } else {
+    if (i >= P1) return;
+    if (i >= (int)lengths1[n]) {  // padded query row: zeros (knn_cpu.cpp:25-26)
+      int64_t* __restrict__ zi = idxs + ((int64_t)n * P1 + i) * K;
+      float* __restrict__ zd = dists + ((int64_t)n * P1 + i) * K;
+      for (int k = 0; k < K; ++k) {
+        zi[k] = 0;
+        zd[k] = 0.0f;
+      }
+      return;
     }
-    return;
   }
-
+  const int64_t row = (int64_t)n * P1 + i;
   float a[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) a[d] = p1[row * D + d];
-
   TopK<KC> top;
   top.init();
-
-  const float* __restrict__ q = p2 + (int64_t)n * P2 * D;  // wave-uniform base
-  int j = 0;
-  for (; j + kTileP2 <= len2; j += kTileP2) {
-    float t[kTileP2 * D];
-#pragma unroll
-    for (int u = 0; u < kTileP2 * D; ++u) t[u] = q[(int64_t)j * D + u];  // uniform -> s_load
-#pragma unroll
-    for (int jj = 0; jj < kTileP2; ++jj) {
-      const float dist = pair_dist<D, NORM>(a, t + jj * D);
-      if (dist < top.worst()) top.insert(dist, j + jj);
-    }
-  }
-  for (; j < len2; ++j) {
-    float t[D];
-#pragma unroll
-    for (int u = 0; u < D; ++u) t[u] = q[(int64_t)j * D + u];
-    const float dist = pair_dist<D, NORM>(a, t);
-    if (dist < top.worst()) top.insert(dist, j);
-  }
-
-  const int kvalid = len2 < K ? len2 : K;
-#pragma unroll
-  for (int k = 0; k < KC; ++k) {
-    if (k < K) {
-      const bool ok = k < kvalid;
-      orow_i[k] = ok ? (int64_t)top.ik[k] : 0;
-      orow_d[k] = ok ? top.dk[k] : 0.0f;
-    }
-  }
+  scan_cloud<D, KC, NORM>(a, p2 + (int64_t)n * P2 * D, len2, top);
+  write_row<KC>(top, K, len2, idxs + row * K, dists + row * K);
 }
 
 // ---------------------------------------------------------------------------
@@ -198,21 +127,11 @@ __global__ __launch_bounds__(kKnnBlock) void knn_generic_kernel(
 // ---------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------
-struct KnnArgs {
-  const float *p1, *p2;
-  const int64_t *l1, *l2;
-  int P1, P2, D, K, tiles;
-  int64_t N;
-  int64_t* idxs;
-  float* dists;
-  hipStream_t stream;
-};
-
 template <int D, int KC, int NORM>
 static void launch_reg(const KnnArgs& a) {
   const dim3 grid((unsigned)(a.N * a.tiles));
   hipLaunchKernelGGL((knn_reg_kernel<D, KC, NORM>), grid, dim3(kKnnBlock), 0, a.stream, a.p1, a.p2,
-                     a.l1, a.l2, a.P1, a.P2, a.K, a.tiles, a.idxs, a.dists);
+                     a.l1, a.l2, a.P1, a.P2, a.K, a.tiles, a.qlist, a.qcount, a.idxs, a.dists);
 }
 
 template <int D, int NORM>
@@ -242,6 +161,11 @@ static void dispatch_d(const KnnArgs& a) {
   }
 }
 
+void launch_knn_bruteforce(const KnnArgs& a, int norm) {
+  if (norm == 1) dispatch_d<1>(a);
+  else dispatch_d<2>(a);
+}
+
 }  // namespace pointops
 
 using namespace pointops;
@@ -249,20 +173,37 @@ using namespace pointops;
 extern "C" {
 
 int pointops_knn_check_version(int version, int64_t D, int64_t K) {
-  // Kernel families of this library (the reference's V0..V3 map onto them the
-  // same way: the highest valid version is the fastest; csrc/knn/knn.cu:292-312):
-  //   0 generic (any D, K)   1/2/3 register top-K (D in [1,8], K in [1,32])
+  // Kernel families of this library.  As in the reference (csrc/knn/knn.cu:292-312) the
+  // highest valid version is the fastest and `version` never changes results:
+  //   0 generic (any D, any K; list kept in the output rows)
+  //   1, 2 register top-K brute-force scan (D in [1,8], K in [1,32])
+  //   3 exact grid-pruned search + brute-force fallback (D in [1,3], K in [1,32])
   if (version == 0) return 1;
-  if (version >= 1 && version <= 3) return (D >= 1 && D <= 8 && K >= 1 && K <= 32) ? 1 : 0;
+  if (version == 1 || version == 2) return (D >= 1 && D <= 8 && K >= 1 && K <= 32) ? 1 : 0;
+  if (version == 3) return (D >= 1 && D <= 3 && K >= 1 && K <= 32) ? 1 : 0;
   return 0;
 }
 
-size_t pointops_knn_workspace_bytes(int64_t, int64_t, int64_t, int64_t, int64_t, int) { return 0; }
+static int choose_version(int version, int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K) {
+  if (version >= 0 && version <= 3 && pointops_knn_check_version(version, D, K)) return version;
+  // auto: the grid only pays once the all-pairs scan is long enough to amortise its
+  // (sort + scan) passes; below that the brute-force scan is latency-optimal.
+  if (pointops_knn_check_version(3, D, K) && P2 >= 4096 && P1 * P2 >= (1LL << 24)) return 3;
+  if (pointops_knn_check_version(2, D, K)) return 2;
+  return 0;
+}
+
+size_t pointops_knn_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K,
+                                    int version) {
+  if (N <= 0 || P1 <= 0 || D < 1 || K < 1) return 0;
+  if (choose_version(version, N, P1, P2, D, K) != 3) return 0;
+  return knn_grid_workspace_bytes(N, P1, P2, K);
+}
 
 int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* lengths1,
                             const int64_t* lengths2, int64_t N, int64_t P1, int64_t P2, int64_t D,
                             int norm, int64_t K, int version, int64_t* idxs, float* dists,
-                            void* /*workspace*/, size_t /*workspace_bytes*/, void* stream) {
+                            void* workspace, size_t workspace_bytes, void* stream) {
   POINTOPS_REQUIRE(norm == 1 || norm == 2, "knn_points_idx: norm must be 1 or 2 (got %d)", norm);
   POINTOPS_REQUIRE(N >= 0 && P1 >= 0 && P2 >= 0 && D >= 1 && K >= 1,
                    "knn_points_idx: bad sizes N=%lld P1=%lld P2=%lld D=%lld K=%lld", (long long)N,
@@ -276,14 +217,20 @@ int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* len
   a.p1 = p1; a.p2 = p2; a.l1 = lengths1; a.l2 = lengths2;
   a.P1 = (int)P1; a.P2 = (int)P2; a.D = (int)D; a.K = (int)K; a.N = N;
   a.tiles = (int)ceil_div(P1, kKnnBlock);
+  a.qlist = nullptr; a.qcount = nullptr;
   a.idxs = idxs; a.dists = dists; a.stream = (hipStream_t)stream;
   POINTOPS_REQUIRE(N * a.tiles < (1LL << 31), "knn_points_idx: grid too large");
 
-  int v = version;
-  if (v < 0 || v > 3 || !pointops_knn_check_version(v, D, K)) {
-    v = pointops_knn_check_version(3, D, K) ? 3 : 0;  // like ChooseVersion (knn.cu:305-312)
-  }
-  if (v == 0) {
+  const int v = choose_version(version, N, P1, P2, D, K);
+  if (v == 3) {
+    const size_t need = knn_grid_workspace_bytes(N, P1, P2, K);
+    if (workspace == nullptr || workspace_bytes < need) {
+      set_error("knn_points_idx: workspace of %zu bytes required (got %zu)", need, workspace_bytes);
+      return POINTOPS_EWORKSPACE;
+    }
+    const int rc = knn_grid_run(a, norm, workspace);
+    if (rc != POINTOPS_OK) return rc;
+  } else if (v == 0) {
     const dim3 grid((unsigned)(N * a.tiles));
     if (norm == 1)
       hipLaunchKernelGGL(knn_generic_kernel<1>, grid, dim3(kKnnBlock), 0, a.stream, p1, p2, lengths1,
@@ -292,8 +239,7 @@ int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* len
       hipLaunchKernelGGL(knn_generic_kernel<2>, grid, dim3(kKnnBlock), 0, a.stream, p1, p2, lengths1,
                          lengths2, a.P1, a.P2, a.D, a.K, a.tiles, idxs, dists);
   } else {
-    if (norm == 1) dispatch_d<1>(a);
-    else dispatch_d<2>(a);
+    launch_knn_bruteforce(a, norm);
   }
   return check_launch("knn_points_idx");
 }

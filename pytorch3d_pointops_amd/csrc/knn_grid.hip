@@ -1,0 +1,869 @@
+// knn_grid.hip -- EXACT grid-pruned K nearest neighbours for D <= 3 on gfx950.
+//
+// Same results, bit for bit, as the all-pairs scan (knn.hip) and therefore as the
+// reference CPU kernel (csrc/knn/knn_cpu.cpp:13-69): every candidate distance is the
+// same unfused fp32 expression, the selection key is the same lexicographic
+// (dist, idx), and a query is only answered from a pruned candidate set when a
+// RIGOROUS fp32 lower bound proves that no unvisited point can enter its top-K;
+// every other query is handed to the brute-force scan.  This is SURVEY.md section 8
+// row f1 -- the only route from the VALU floor of the all-pairs scan (~16 ms at
+// B=32, N=M=65536, K=16) towards the HBM floor (72 us).
+//
+// Passes (all clouds of the batch in every launch, no host synchronisation):
+//   1 grid_setup     per cloud: bbox of p2, cubic cell size h for ~K/2 points per cell,
+//                    G = cells per dimension, and per-dimension EDGE TABLES
+//                    E_d[c] = min{ x in [lo,hi] : cell_d(x) >= c }, found by bisection over
+//                    the ordered fp32 bit patterns of the (monotone) cell function
+//                    itself -- no error analysis of the binning arithmetic is needed;
+//   2 grid_count     histogram of p2 points per cell and of p1 queries per BLOCK of
+//                    B^3 cells (atomics); zero rows for padded queries;
+//   3 grid_scan      exclusive scans -> cell_start / blk_start;
+//   4 grid_scatter   counting-sort p2 into (x,y,z,idx) float4 records, queries into
+//                    per-block lists;
+//   5 knn_grid       persistent wave64 workgroups walk (cloud, block) items: the <= 64
+//                    queries of a chunk sit one per lane; the block's cells plus a one
+//                    cell halo are streamed row by row through the SCALAR path (the
+//                    records of a row are contiguous in the sorted array and the address
+//                    is wave-uniform) exactly like the all-pairs scan, but over ~500
+//                    candidates instead of the whole cloud.  Afterwards each lane checks
+//                    kth_dist < LB, LB = min over the region's faces of the bound below;
+//                    on failure the query id goes to the fallback list;
+//   6 fallback       knn_reg_kernel over the fallback lists (whole-cloud scan).
+//
+// Lower bound.  Let the visited region be cells [X0..X1]x[Y0..Y1]x[Z0..Z1].  A point in
+// an unvisited cell has, in some dimension d, cell_d < X0 or cell_d > X1.  cell_d is
+// monotone in the coordinate, so p_d <= prev(E_d[X0]) =: f or p_d >= E_d[X1+1] =: f.  fp32
+// subtraction and multiplication by itself are monotone, so the COMPUTED |q_d - p_d| is
+// >= fl(|q_d - f|) and the computed square >= fl(fl(|q_d - f|)^2); adding the other
+// (non-negative) terms and rounding cannot go below that.  Hence the computed distance
+// of every unvisited point is >= LB, and `kth < LB` (strict) also rules out ties.
+#include <float.h>
+#include <math.h>
+
+#include "knn_common.h"
+#include "knn_grid.h"
+
+namespace pointops {
+
+constexpr int kGMax = 1024;          // cells per dimension cap (edge table size)
+constexpr int kEdgeStride = kGMax + 2;
+constexpr int kSetupBlock = 256;
+constexpr int kScanBlock = 1024;
+constexpr int kGridWave = 64;
+
+struct GridCloud {
+  float lo[3];
+  float inv_h;
+  int G[3];
+  int NB[3];
+  int ncell, nblock;
+  int len1, len2;
+  int use_grid;
+  int B;
+};
+
+struct GridWs {
+  GridCloud* cloud;   // N
+  int* block_prefix;  // N + 1
+  float* edges;       // N * 3 * kEdgeStride
+  int* cell_count;    // N * cell_cap   histogram, then scatter cursor
+  int* cell_start;    // N * (cell_cap + 1)
+  float4* sorted;     // N * P2         (x, y, z, idx bits)
+  int* blk_count;     // N * cell_cap
+  int* blk_start;     // N * (cell_cap + 1)
+  int* qlist;         // N * P1         query ids grouped by block
+  int* fb_count;      // N          queries the block search could not certify
+  int* fb_list;       // N * P1
+  int* fb2_count;     // N          queries the expanding search gave up on (whole-cloud scan)
+  int* fb2_list;      // N * P1
+  int cell_cap;
+};
+
+// ---------------------------------------------------------------------------
+// monotone cell function and ordered fp32 keys
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int cell_of(float x, float lo, float inv_h, int G) {
+  const float t = (x - lo) * inv_h;  // unfused; monotone non-decreasing in x
+  int c = (t < (float)G) ? (int)t : G - 1;
+  if (!(t >= 0.0f)) c = 0;  // below the box, or NaN
+  return c;
+}
+__device__ __forceinline__ unsigned fkey(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float funkey(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ float prev_float(float x) { return funkey(fkey(x) - 1u); }
+
+// smallest x in [lo, hi] with cell_of(x) >= c, +inf if none
+__device__ float edge_bisect(int c, float lo, float hi, float inv_h, int G) {
+  if (c <= 0) return lo;
+  if (cell_of(hi, lo, inv_h, G) < c) return __builtin_inff();
+  unsigned a = fkey(lo), b = fkey(hi);
+  while (a < b) {
+    const unsigned m = a + (b - a) / 2u;
+    if (cell_of(funkey(m), lo, inv_h, G) >= c) b = m;
+    else a = m + 1u;
+  }
+  return funkey(a);
+}
+
+// ---------------------------------------------------------------------------
+// pass 1: per-cloud grid parameters + edge tables
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
+    const float* __restrict__ p2, const int64_t* __restrict__ lengths1,
+    const int64_t* __restrict__ lengths2, int P1, int P2, int D, float c_target, int B, GridWs ws) {
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  int len2 = (int)lengths2[n];
+  len2 = len2 < 0 ? 0 : (len2 > P2 ? P2 : len2);
+  int len1 = (int)lengths1[n];
+  len1 = len1 < 0 ? 0 : (len1 > P1 ? P1 : len1);
+
+  float mn[3], mx[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    mn[d] = __builtin_inff();
+    mx[d] = -__builtin_inff();
+  }
+  const float* __restrict__ base = p2 + (int64_t)n * P2 * D;
+  for (int j = tid; j < len2; j += kSetupBlock) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (d < D) {
+        const float v = base[(int64_t)j * D + d];
+        mn[d] = fminf(mn[d], v);
+        mx[d] = fmaxf(mx[d], v);
+      }
+    }
+  }
+  __shared__ float s_mn[3][kSetupBlock / kWave], s_mx[3][kSetupBlock / kWave];
+  __shared__ GridCloud s_g;
+  __shared__ float s_hi[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+      mn[d] = fminf(mn[d], __shfl_xor(mn[d], off, kWave));
+      mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, kWave));
+    }
+    if ((tid & (kWave - 1)) == 0) {
+      s_mn[d][tid / kWave] = mn[d];
+      s_mx[d][tid / kWave] = mx[d];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    GridCloud g;
+    float lo[3], hi[3], e[3];
+    bool finite = len2 > 0;
+    for (int d = 0; d < 3; ++d) {
+      float a = __builtin_inff(), b = -__builtin_inff();
+      for (int w = 0; w < kSetupBlock / kWave; ++w) {
+        a = fminf(a, s_mn[d][w]);
+        b = fmaxf(b, s_mx[d][w]);
+      }
+      if (d >= D) a = b = 0.0f;  // padded dimensions
+      lo[d] = a;
+      hi[d] = b;
+      e[d] = b - a;
+      if (!(fabsf(a) <= FLT_MAX) || !(fabsf(b) <= FLT_MAX) || !(e[d] <= FLT_MAX)) finite = false;
+    }
+    // cubic cells of edge h with ~c_target points each over the non-degenerate dimensions
+    bool active[3] = {e[0] > 0.0f, e[1] > 0.0f, e[2] > 0.0f};
+    float h = 0.0f;
+    const float target_cells = fmaxf(1.0f, (float)len2 / c_target);
+    if (finite) {
+      for (int it = 0; it < 4; ++it) {
+        int k = 0;
+        double vol = 1.0;
+        for (int d = 0; d < 3; ++d)
+          if (active[d]) {
+            ++k;
+            vol *= (double)e[d];
+          }
+        if (k == 0) break;
+        h = (float)pow(vol / (double)target_cells, 1.0 / (double)k);
+        bool changed = false;
+        for (int d = 0; d < 3; ++d)
+          if (active[d] && !(e[d] >= h)) {
+            active[d] = false;
+            changed = true;
+          }
+        if (!changed) break;
+      }
+    }
+    const bool any_active = active[0] || active[1] || active[2];
+    bool ok = finite && (!any_active || (h > 0.0f && h <= FLT_MAX));
+    float inv_h = 1.0f;
+    int G[3] = {1, 1, 1};
+    if (ok && any_active) {
+      for (int it = 0; it < 64; ++it) {
+        inv_h = 1.0f / h;
+        if (!(inv_h > 0.0f && inv_h <= FLT_MAX)) {
+          ok = false;
+          break;
+        }
+        long long cells = 1;
+        for (int d = 0; d < 3; ++d) {
+          G[d] = 1;
+          if (active[d]) {
+            const float t = e[d] * inv_h;  // same expression as cell_of(hi)
+            G[d] = (t < (float)kGMax) ? (int)t + 1 : kGMax;
+            if (G[d] < 1) G[d] = 1;
+          }
+          cells *= G[d];
+        }
+        if (cells <= (long long)ws.cell_cap) break;
+        h *= 1.2599211f;  // halve the cell count and retry
+      }
+      if ((long long)G[0] * G[1] * G[2] > (long long)ws.cell_cap) ok = false;
+    }
+    for (int d = 0; d < 3; ++d) {
+      g.lo[d] = lo[d];
+      g.G[d] = G[d];
+      g.NB[d] = (G[d] + B - 1) / B;
+      s_hi[d] = hi[d];
+    }
+    g.inv_h = inv_h;
+    g.ncell = G[0] * G[1] * G[2];
+    g.nblock = g.NB[0] * g.NB[1] * g.NB[2];
+    g.len1 = len1;
+    g.len2 = len2;
+    g.use_grid = ok ? 1 : 0;
+    g.B = B;
+    s_g = g;
+    ws.cloud[n] = g;
+    ws.fb_count[n] = 0;
+    ws.fb2_count[n] = 0;
+  }
+  __syncthreads();
+  if (s_g.use_grid) {
+    float* __restrict__ ed = ws.edges + (int64_t)n * 3 * kEdgeStride;
+    for (int t = tid; t < 3 * kEdgeStride; t += kSetupBlock) {
+      const int d = t / kEdgeStride, c = t - d * kEdgeStride;
+      const int G = s_g.G[d];
+      ed[t] = (c <= G) ? edge_bisect(c, s_g.lo[d], s_hi[d], s_g.inv_h, G) : __builtin_inff();
+    }
+  }
+}
+
+// prefix of blocks over clouds (work decode of the persistent kernel)
+__global__ void grid_prefix_kernel(GridWs ws, int N) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int acc = 0;
+    ws.block_prefix[0] = 0;
+    for (int n = 0; n < N; ++n) {
+      const GridCloud g = ws.cloud[n];
+      acc += g.use_grid ? g.nblock : 0;
+      ws.block_prefix[n + 1] = acc;
+    }
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void load_point3(const float* __restrict__ p, float& x, float& y, float& z) {
+  x = p[0];
+  y = D > 1 ? p[1] : 0.0f;
+  z = D > 2 ? p[2] : 0.0f;
+}
+
+__device__ __forceinline__ void point_cells(const GridCloud& g, float x, float y, float z, int& cx, int& cy,
+                                            int& cz) {
+  cx = cell_of(x, g.lo[0], g.inv_h, g.G[0]);
+  cy = cell_of(y, g.lo[1], g.inv_h, g.G[1]);
+  cz = cell_of(z, g.lo[2], g.inv_h, g.G[2]);
+}
+
+// ---------------------------------------------------------------------------
+// pass 2 / 4: histogram and counting-sort scatter (SCATTER = false / true)
+// ---------------------------------------------------------------------------
+template <int D, bool SCATTER>
+__global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__ p1,
+                                                       const float* __restrict__ p2, int P1, int P2, int K,
+                                                       GridWs ws, int64_t* __restrict__ idxs,
+                                                       float* __restrict__ dists) {
+  const int n = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const GridCloud g = ws.cloud[n];  // wave-uniform
+  const int64_t cbase = (int64_t)n * ws.cell_cap;
+  if (g.use_grid && i < g.len2) {
+    float x, y, z;
+    load_point3<D>(p2 + ((int64_t)n * P2 + i) * D, x, y, z);
+    int cx, cy, cz;
+    point_cells(g, x, y, z, cx, cy, cz);
+    const int cell = (cz * g.G[1] + cy) * g.G[0] + cx;
+    if (!SCATTER) {
+      atomicAdd(ws.cell_count + cbase + cell, 1);
+    } else {
+      const int pos = ws.cell_start[(int64_t)n * (ws.cell_cap + 1) + cell] + atomicAdd(ws.cell_count + cbase + cell, 1);
+      ws.sorted[(int64_t)n * P2 + pos] = make_float4(x, y, z, __int_as_float(i));
+    }
+  }
+  if (i < P1) {
+    if (i >= g.len1) {
+      if (!SCATTER) {  // padded query row: zeros (knn_cpu.cpp:25-26)
+        int64_t* __restrict__ zi = idxs + ((int64_t)n * P1 + i) * K;
+        float* __restrict__ zd = dists + ((int64_t)n * P1 + i) * K;
+        for (int k = 0; k < K; ++k) {
+          zi[k] = 0;
+          zd[k] = 0.0f;
+        }
+      }
+    } else if (g.use_grid) {
+      float x, y, z;
+      load_point3<D>(p1 + ((int64_t)n * P1 + i) * D, x, y, z);
+      int cx, cy, cz;
+      point_cells(g, x, y, z, cx, cy, cz);
+      const int b = ((cz / g.B) * g.NB[1] + (cy / g.B)) * g.NB[0] + (cx / g.B);
+      if (!SCATTER) {
+        atomicAdd(ws.blk_count + cbase + b, 1);
+      } else {
+        const int pos = ws.blk_start[(int64_t)n * (ws.cell_cap + 1) + b] + atomicAdd(ws.blk_count + cbase + b, 1);
+        ws.qlist[(int64_t)n * P1 + pos] = i;
+      }
+    } else if (!SCATTER) {  // no usable grid for this cloud: whole-cloud scan
+      const int pos = atomicAdd(ws.fb2_count + n, 1);
+      ws.fb2_list[(int64_t)n * P1 + pos] = i;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 3: exclusive scans (one workgroup per cloud); counts are reset to 0 so
+// they can serve as scatter cursors.
+// ---------------------------------------------------------------------------
+__device__ void block_exclusive_scan_inplace(int* __restrict__ count, int* __restrict__ start, int n) {
+  __shared__ int s_part[kScanBlock / kWave];
+  __shared__ int s_total;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int per = (n + kScanBlock - 1) / kScanBlock;
+  const int b = tid * per;
+  const int e = (b + per < n) ? b + per : n;
+  int sum = 0;
+  for (int i = b; i < e; ++i) sum += count[i];
+  // inclusive wave scan of the per-thread sums
+  int inc = sum;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int v = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += v;
+  }
+  if (lane == kWave - 1) s_part[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    int v = lane < kScanBlock / kWave ? s_part[lane] : 0;
+    int winc = v;
+#pragma unroll
+    for (int off = 1; off < kScanBlock / kWave; off <<= 1) {
+      const int u = __shfl_up(winc, off, kWave);
+      if (lane >= off) winc += u;
+    }
+    if (lane < kScanBlock / kWave) s_part[lane] = winc - v;  // exclusive wave offsets
+    if (lane == kScanBlock / kWave - 1) s_total = winc;
+  }
+  __syncthreads();
+  int run = s_part[wave] + inc - sum;
+  for (int i = b; i < e; ++i) {
+    const int c = count[i];
+    start[i] = run;
+    run += c;
+    count[i] = 0;
+  }
+  if (tid == 0) start[n] = s_total;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kScanBlock) void grid_scan_kernel(GridWs ws) {
+  const int n = blockIdx.x;
+  const GridCloud g = ws.cloud[n];
+  if (!g.use_grid) return;
+  block_exclusive_scan_inplace(ws.cell_count + (int64_t)n * ws.cell_cap,
+                               ws.cell_start + (int64_t)n * (ws.cell_cap + 1), g.ncell);
+  block_exclusive_scan_inplace(ws.blk_count + (int64_t)n * ws.cell_cap,
+                               ws.blk_start + (int64_t)n * (ws.cell_cap + 1), g.nblock);
+}
+
+// ---------------------------------------------------------------------------
+// pass 5: the search.  One wave64 per workgroup, persistent over (cloud, block) items.
+//
+// The candidate records of a block's region (block cells + one-cell halo) form a
+// FLAT STREAM: row (z,y) contributes the contiguous run cell_start[row,X0] ..
+// cell_start[row,X1+1] of the sorted array.  The stream is consumed in tiles of 64
+// records: lane t fetches record t of the tile with one coalesced 16-byte load
+// (issued one tile ahead, T14-style split of load and LDS write), parks it in LDS,
+// and the scan loop then reads record after record with a wave-uniform
+// ds_read_b128 -- a broadcast that delivers the candidate in VGPRs, so the eight
+// distance ops run at the full VALU rate (an SGPR-sourced operand costs 1.5x:
+// profiles/r01_valu_microbench.txt).
+// ---------------------------------------------------------------------------
+template <int NORM>
+__device__ __forceinline__ float face_bound(float t) {  // t = fl(|q - face|) >= 0
+  return NORM == 1 ? t : t * t;
+}
+
+constexpr int kMaxRows = 100;  // (B + 2)^2 with B <= 8
+
+template <int D, int KC, int NORM>
+__global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
+    const float* __restrict__ p1, const GridCloud* __restrict__ clouds,
+    const int* __restrict__ block_prefix, const float* __restrict__ edges,
+    const int* __restrict__ cell_start, const float4* __restrict__ sorted,
+    const int* __restrict__ blk_start, const int* __restrict__ qlist, int* __restrict__ fb_count,
+    int* __restrict__ fb_list, int cell_cap, int P1, int P2, int K, int N, int64_t* __restrict__ idxs,
+    float* __restrict__ dists) {
+  // Per-lane candidate queues (KC >= 8): a candidate that beats the lane's (possibly stale)
+  // threshold is parked with one ds_write_b64; the sorted register list is only updated
+  // when some lane's queue is full, by ALL lanes together.  Without this almost every
+  // candidate makes the whole wave walk the ~100-instruction insert for one or two lanes.
+  constexpr bool kUseQueue = false;
+  constexpr int kQueueCap = 8;
+  __shared__ unsigned long long s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
+  __shared__ float4 s_tile[2][kGridWave];
+  __shared__ int s_rowsrc[kMaxRows];  // first record of the row's run in `sorted`
+  __shared__ int s_rowoff[kMaxRows + 1];  // position of the row in the flat stream
+
+  const int lane = threadIdx.x;
+  const int total = block_prefix[N];
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    // cloud of this item: largest n with block_prefix[n] <= item (uniform binary search)
+    int lo_n = 0, hi_n = N;
+    while (hi_n - lo_n > 1) {
+      const int mid = (lo_n + hi_n) >> 1;
+      if (block_prefix[mid] <= item) lo_n = mid;
+      else hi_n = mid;
+    }
+    const int n = lo_n;
+    const int b = item - block_prefix[n];
+    const int* __restrict__ bstart = blk_start + (int64_t)n * (cell_cap + 1);
+    const int qs = bstart[b], qe = bstart[b + 1];
+    if (qs == qe) continue;
+
+    const GridCloud g = clouds[n];
+    const int bx = b % g.NB[0], by = (b / g.NB[0]) % g.NB[1], bz = b / (g.NB[0] * g.NB[1]);
+    const int X0 = max(bx * g.B - 1, 0), X1 = min(bx * g.B + g.B, g.G[0] - 1);
+    const int Y0 = max(by * g.B - 1, 0), Y1 = min(by * g.B + g.B, g.G[1] - 1);
+    const int Z0 = max(bz * g.B - 1, 0), Z1 = min(bz * g.B + g.B, g.G[2] - 1);
+    const float* __restrict__ ed = edges + (int64_t)n * 3 * kEdgeStride;
+    // faces of the visited region (wave-uniform); a missing face = the grid boundary
+    const bool hx0 = X0 > 0, hx1 = X1 < g.G[0] - 1;
+    const bool hy0 = Y0 > 0, hy1 = Y1 < g.G[1] - 1;
+    const bool hz0 = Z0 > 0, hz1 = Z1 < g.G[2] - 1;
+    const float fx0 = hx0 ? prev_float(ed[X0]) : 0.0f, fx1 = hx1 ? ed[X1 + 1] : 0.0f;
+    const float fy0 = hy0 ? prev_float(ed[kEdgeStride + Y0]) : 0.0f, fy1 = hy1 ? ed[kEdgeStride + Y1 + 1] : 0.0f;
+    const float fz0 = hz0 ? prev_float(ed[2 * kEdgeStride + Z0]) : 0.0f,
+                fz1 = hz1 ? ed[2 * kEdgeStride + Z1 + 1] : 0.0f;
+    const bool whole = !(hx0 || hx1 || hy0 || hy1 || hz0 || hz1);
+
+    // row table of the region's flat candidate stream
+    const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
+    const int ny = Y1 - Y0 + 1, nrows = ny * (Z1 - Z0 + 1);
+    __syncthreads();  // previous item's readers are done with the tables
+    // Rows are visited NEAR-FIRST: the block's own cells, then the halo.  After the block's own
+    // points the per-lane thresholds are almost final, so halo candidates rarely pass.
+    const int zb0 = bz * g.B, nbz = min(zb0 + g.B - 1, g.G[2] - 1) - zb0 + 1;
+    const int yb0 = by * g.B, nby = min(yb0 + g.B - 1, g.G[1] - 1) - yb0 + 1;
+    for (int r = lane; r < nrows; r += kGridWave) {  // nrows <= 100
+      const int iz = r / ny, iy = r % ny;
+      const int z = iz < nbz ? zb0 + iz : ((Z0 < zb0 && iz == nbz) ? Z0 : Z1);
+      const int y = iy < nby ? yb0 + iy : ((Y0 < yb0 && iy == nby) ? Y0 : Y1);
+      const int rowbase = (z * g.G[1] + y) * g.G[0];
+      const int s = cstart[rowbase + X0], e = cstart[rowbase + X1 + 1];
+      s_rowsrc[r] = s;
+      s_rowoff[r + 1] = e - s;  // lengths first, scanned below
+    }
+    __syncthreads();
+    if (lane == 0) {
+      int acc = 0;
+      s_rowoff[0] = 0;
+      for (int r = 0; r < nrows; ++r) {
+        acc += s_rowoff[r + 1];
+        s_rowoff[r + 1] = acc;
+      }
+    }
+    __syncthreads();
+    const int T = s_rowoff[nrows];  // records in the region
+    const float4* __restrict__ sp = sorted + (int64_t)n * P2;
+    const int* __restrict__ ql = qlist + (int64_t)n * P1;
+
+    // record t of the flat stream -> its address (per lane); `rh` = a row at or before t's row
+    auto fetch = [&](int t, int rh) -> float4 {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < T) {
+        int r = rh;
+        while (s_rowoff[r + 1] <= t) ++r;  // t < T = rowoff[nrows] bounds the walk
+        v = sp[s_rowsrc[r] + (t - s_rowoff[r])];
+      }
+      return v;
+    };
+
+    for (int c0 = qs; c0 < qe; c0 += kGridWave) {
+      const bool active = c0 + lane < qe;
+      const int qi = active ? ql[c0 + lane] : 0;
+      float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+      if (active) load_point3<D>(p1 + ((int64_t)n * P1 + qi) * D, qx, qy, qz);
+
+      TopKLex<KC> top;
+      top.init();
+      unsigned thr = 0x7f800000u;  // distance bits a candidate must not exceed (stale between flushes)
+      int qn = 0;                  // entries in this lane's queue
+      auto flush = [&]() {
+        for (int t = 0; __any(t < qn); ++t) {
+          if (t < qn) {
+            const unsigned long long key = s_queue[t * kGridWave + lane];
+            if (key < top.key[KC - 1]) top.insert(key);
+          }
+        }
+        qn = 0;
+        thr = top.worst_bits();
+      };
+      float4 nxt = fetch(lane, 0);
+      int buf = 0;
+      int rhint = 0;  // wave-uniform: row containing the first record of the NEXT tile
+      for (int t0 = 0; t0 < T; t0 += kGridWave) {
+        __syncthreads();  // tile `buf` no longer read (two tiles ago)
+        s_tile[buf][lane] = nxt;
+        if (t0 + kGridWave < T) {
+          while (s_rowoff[rhint + 1] <= t0 + kGridWave) ++rhint;
+        }
+        nxt = fetch(t0 + kGridWave + lane, rhint);  // next tile's loads fly during this tile's scan
+        __syncthreads();
+        const int cnt = min(kGridWave, T - t0);
+#pragma unroll 4
+        for (int t = 0; t < cnt; ++t) {
+          const float4 c = s_tile[buf][t];  // wave-uniform LDS address: broadcast read
+          float d;
+          if (NORM == 1) {
+            d = __builtin_fabsf(qx - c.x);
+            if (D > 1) d = d + __builtin_fabsf(qy - c.y);
+            if (D > 2) d = d + __builtin_fabsf(qz - c.z);
+          } else {
+            const float dx = qx - c.x;
+            d = dx * dx;
+            if (D > 1) {
+              const float dy = qy - c.y;
+              d = d + dy * dy;
+            }
+            if (D > 2) {
+              const float dz = qz - c.z;
+              d = d + dz * dz;
+            }
+          }
+          if (kUseQueue) {
+            if (__float_as_uint(d) <= thr) {
+              s_queue[qn * kGridWave + lane] = TopKLex<KC>::make(d, __float_as_int(c.w));
+              ++qn;
+            }
+            if (__any(qn == kQueueCap)) flush();
+          } else if (__float_as_uint(d) <= top.worst_bits()) {
+            const unsigned long long key = TopKLex<KC>::make(d, __float_as_int(c.w));
+            if (key < top.key[KC - 1]) top.insert(key);
+          }
+        }
+        buf ^= 1;
+      }
+      if (kUseQueue) flush();
+      // Acceptance: the KC-th best (KC >= K: conservative) against the rigorous lower bound
+      // of every point that was not visited.
+      const unsigned kth_bits = top.worst_bits();
+      float lb = __builtin_inff();
+      if (hx0) lb = fminf(lb, face_bound<NORM>(qx - fx0));
+      if (hx1) lb = fminf(lb, face_bound<NORM>(fx1 - qx));
+      if (hy0) lb = fminf(lb, face_bound<NORM>(qy - fy0));
+      if (hy1) lb = fminf(lb, face_bound<NORM>(fy1 - qy));
+      if (hz0) lb = fminf(lb, face_bound<NORM>(qz - fz0));
+      if (hz1) lb = fminf(lb, face_bound<NORM>(fz1 - qz));
+      const bool full = kth_bits < 0x7f800000u;
+      const bool ok = whole || (full && __uint_as_float(kth_bits) < lb);
+      if (active) {
+        if (ok) {
+          const int64_t row = (int64_t)n * P1 + qi;
+          write_row<KC>(top, K, g.len2, idxs + row * K, dists + row * K);
+        } else {
+          const int pos = atomicAdd(fb_count + n, 1);
+          fb_list[(int64_t)n * P1 + pos] = qi;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 6: wave-per-query EXPANDING search for the queries pass 5 could not certify
+// (typically < 1 % of a cloud).  The wave's 64 lanes split the candidate records of
+// the cube of cells [c - r, c + r]^3 around the query's cell (coalesced 16-byte
+// loads along each row's contiguous run), keep a private lexicographic top-K each,
+// and K rounds of a wave-wide 64-bit min extract the K global minima.  The same
+// rigorous face bound decides; on failure r doubles, until the cube is the whole
+// grid (always exact) or more than kWaveRegionCap records were scanned, in which
+// case the query goes to the whole-cloud lane-per-query scan (far-away queries).
+// ---------------------------------------------------------------------------
+constexpr int kWaveKernelBlock = 256;
+constexpr int kWaveKernelWgsPerCloud = 64;
+constexpr int kWaveRegionCap = 16384;
+
+template <int D, int KC, int NORM>
+__global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
+    const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const float* __restrict__ edges,
+    const int* __restrict__ cell_start, const float4* __restrict__ sorted, const int* __restrict__ fb_count,
+    const int* __restrict__ fb_list, int* __restrict__ fb2_count, int* __restrict__ fb2_list, int cell_cap,
+    int P1, int P2, int K, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+  const int n = blockIdx.y;
+  const int cnt = fb_count[n];
+  if (cnt == 0) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = blockIdx.x * (kWaveKernelBlock / kWave) + threadIdx.x / kWave;
+  constexpr int kWavesPerCloud = kWaveKernelWgsPerCloud * (kWaveKernelBlock / kWave);
+  const GridCloud g = clouds[n];
+  const float* __restrict__ ed = edges + (int64_t)n * 3 * kEdgeStride;
+  const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
+  const float4* __restrict__ sp = sorted + (int64_t)n * P2;
+  const int kvalid = g.len2 < K ? g.len2 : K;
+
+  for (int w = wave; w < cnt; w += kWavesPerCloud) {
+    const int qi = fb_list[(int64_t)n * P1 + w];  // wave-uniform
+    const int64_t row = (int64_t)n * P1 + qi;
+    float qx, qy, qz;
+    load_point3<D>(p1 + row * D, qx, qy, qz);
+    int cx, cy, cz;
+    point_cells(g, qx, qy, qz, cx, cy, cz);
+    bool done = false;
+    for (int r = 2; !done; r *= 2) {
+      const int X0 = max(cx - r, 0), X1 = min(cx + r, g.G[0] - 1);
+      const int Y0 = max(cy - r, 0), Y1 = min(cy + r, g.G[1] - 1);
+      const int Z0 = max(cz - r, 0), Z1 = min(cz + r, g.G[2] - 1);
+      const bool hx0 = X0 > 0, hx1 = X1 < g.G[0] - 1;
+      const bool hy0 = Y0 > 0, hy1 = Y1 < g.G[1] - 1;
+      const bool hz0 = Z0 > 0, hz1 = Z1 < g.G[2] - 1;
+      const bool whole = !(hx0 || hx1 || hy0 || hy1 || hz0 || hz1);
+      TopKLex<KC> top;
+      top.init();
+      int scanned = 0;
+      bool giveup = false;
+      for (int z = Z0; z <= Z1 && !giveup; ++z) {
+        for (int y = Y0; y <= Y1; ++y) {
+          const int rowbase = (z * g.G[1] + y) * g.G[0];
+          const int s = cstart[rowbase + X0], e = cstart[rowbase + X1 + 1];
+          for (int j = s + lane; j < e; j += kWave) {
+            const float4 c = sp[j];
+            float d;
+            if (NORM == 1) {
+              d = __builtin_fabsf(qx - c.x);
+              if (D > 1) d = d + __builtin_fabsf(qy - c.y);
+              if (D > 2) d = d + __builtin_fabsf(qz - c.z);
+            } else {
+              const float dx = qx - c.x;
+              d = dx * dx;
+              if (D > 1) {
+                const float dy = qy - c.y;
+                d = d + dy * dy;
+              }
+              if (D > 2) {
+                const float dz = qz - c.z;
+                d = d + dz * dz;
+              }
+            }
+            if (__float_as_uint(d) <= top.worst_bits()) {
+              const unsigned long long key = TopKLex<KC>::make(d, __float_as_int(c.w));
+              if (key < top.key[KC - 1]) top.insert(key);
+            }
+          }
+          scanned += e - s;
+        }
+        if (!whole && scanned > kWaveRegionCap) giveup = true;
+      }
+      if (giveup) {
+        if (lane == 0) {
+          const int pos = atomicAdd(fb2_count + n, 1);
+          fb2_list[(int64_t)n * P1 + pos] = qi;
+        }
+        break;
+      }
+      // K rounds: wave-wide lexicographic minimum of the list heads; the (unique) winner pops
+      unsigned long long mine = TopKLex<KC>::kEmpty, kth = TopKLex<KC>::kEmpty;
+      for (int k = 0; k < kvalid; ++k) {
+        unsigned long long m = top.key[0];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+          const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(m >> 32), off, kWave);
+          const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)m, off, kWave);
+          const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+          m = o < m ? o : m;
+        }
+        if (lane == k) mine = m;
+        kth = m;
+        if (top.key[0] == m) {
+#pragma unroll
+          for (int s2 = 0; s2 + 1 < KC; ++s2) top.key[s2] = top.key[s2 + 1];
+          top.key[KC - 1] = TopKLex<KC>::kEmpty;
+        }
+      }
+      float lb = __builtin_inff();
+      if (hx0) lb = fminf(lb, face_bound<NORM>(qx - prev_float(ed[X0])));
+      if (hx1) lb = fminf(lb, face_bound<NORM>(ed[X1 + 1] - qx));
+      if (hy0) lb = fminf(lb, face_bound<NORM>(qy - prev_float(ed[kEdgeStride + Y0])));
+      if (hy1) lb = fminf(lb, face_bound<NORM>(ed[kEdgeStride + Y1 + 1] - qy));
+      if (hz0) lb = fminf(lb, face_bound<NORM>(qz - prev_float(ed[2 * kEdgeStride + Z0])));
+      if (hz1) lb = fminf(lb, face_bound<NORM>(ed[2 * kEdgeStride + Z1 + 1] - qz));
+      const unsigned kth_bits = (unsigned)(kth >> 32);
+      const bool full = kvalid == K && kth_bits < 0x7f800000u;
+      if (whole || (full && __uint_as_float(kth_bits) < lb)) {
+        if (lane < K) {
+          const bool ok = lane < kvalid;
+          idxs[row * K + lane] = ok ? (int64_t)(int)(unsigned)mine : 0;
+          dists[row * K + lane] = ok ? __uint_as_float((unsigned)(mine >> 32)) : 0.0f;
+        }
+        done = true;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int grid_kc(int K) { return K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : K <= 24 ? 24 : 32; }
+
+static void grid_tuning(int K, float* c_target, int* B) {
+  // the search keeps the KC >= K best and certifies the KC-th, so size the cells for KC
+  float c = 0.5f * (float)grid_kc(K);
+  if (c < 1.0f) c = 1.0f;
+  int b = (int)lround(cbrt(64.0 / (double)c));  // ~64 queries (one wave) per block
+  if (b < 1) b = 1;
+  if (b > 8) b = 8;
+  *c_target = c;
+  *B = b;
+}
+
+static int grid_cell_cap(int64_t P2, float c_target) {
+  const int64_t cells = (int64_t)ceil((double)P2 / (double)c_target);
+  return (int)(2 * cells + 64);
+}
+
+static size_t carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, int K) {
+  float c;
+  int B;
+  grid_tuning(K, &c, &B);
+  const int cap = grid_cell_cap(P2, c);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes);
+    return p;
+  };
+  GridWs w;
+  w.cell_cap = cap;
+  w.cloud = (GridCloud*)take(sizeof(GridCloud) * (size_t)N);
+  w.block_prefix = (int*)take(sizeof(int) * (size_t)(N + 1));
+  w.edges = (float*)take(sizeof(float) * (size_t)N * 3 * kEdgeStride);
+  w.cell_count = (int*)take(sizeof(int) * (size_t)N * cap);
+  w.blk_count = (int*)take(sizeof(int) * (size_t)N * cap);  // adjacent to cell_count: one memset
+  w.cell_start = (int*)take(sizeof(int) * (size_t)N * (cap + 1));
+  w.blk_start = (int*)take(sizeof(int) * (size_t)N * (cap + 1));
+  w.sorted = (float4*)take(sizeof(float4) * (size_t)N * (size_t)P2);
+  w.qlist = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
+  w.fb_count = (int*)take(sizeof(int) * (size_t)N);
+  w.fb_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
+  w.fb2_count = (int*)take(sizeof(int) * (size_t)N);
+  w.fb2_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
+  if (ws) *ws = w;
+  return off;
+}
+
+size_t knn_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K) {
+  return carve(nullptr, nullptr, N, P1, P2, (int)K);
+}
+
+template <int D, int KC, int NORM>
+static void launch_grid_search(const KnnArgs& a, const GridWs& ws, int wgs) {
+  hipLaunchKernelGGL((knn_grid_kernel<D, KC, NORM>), dim3((unsigned)wgs), dim3(kGridWave), 0, a.stream, a.p1,
+                     (const GridCloud*)ws.cloud, (const int*)ws.block_prefix, (const float*)ws.edges,
+                     (const int*)ws.cell_start, (const float4*)ws.sorted, (const int*)ws.blk_start,
+                     (const int*)ws.qlist, ws.fb_count, ws.fb_list, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N,
+                     a.idxs, a.dists);
+}
+
+template <int D, int KC, int NORM>
+static void launch_grid_wave(const KnnArgs& a, const GridWs& ws) {
+  hipLaunchKernelGGL((knn_grid_wave_kernel<D, KC, NORM>), dim3(kWaveKernelWgsPerCloud, (unsigned)a.N),
+                     dim3(kWaveKernelBlock), 0, a.stream, a.p1, (const GridCloud*)ws.cloud, (const float*)ws.edges,
+                     (const int*)ws.cell_start, (const float4*)ws.sorted, (const int*)ws.fb_count,
+                     (const int*)ws.fb_list, ws.fb2_count, ws.fb2_list, ws.cell_cap, a.P1, a.P2, a.K, a.idxs,
+                     a.dists);
+}
+
+template <int D, int NORM>
+static void dispatch_grid_k(const KnnArgs& a, const GridWs& ws, int wgs) {
+  const int K = a.K;
+  if (K <= 1) { launch_grid_search<D, 1, NORM>(a, ws, wgs); launch_grid_wave<D, 1, NORM>(a, ws); }
+  else if (K <= 2) { launch_grid_search<D, 2, NORM>(a, ws, wgs); launch_grid_wave<D, 2, NORM>(a, ws); }
+  else if (K <= 4) { launch_grid_search<D, 4, NORM>(a, ws, wgs); launch_grid_wave<D, 4, NORM>(a, ws); }
+  else if (K <= 8) { launch_grid_search<D, 8, NORM>(a, ws, wgs); launch_grid_wave<D, 8, NORM>(a, ws); }
+  else if (K <= 16) { launch_grid_search<D, 16, NORM>(a, ws, wgs); launch_grid_wave<D, 16, NORM>(a, ws); }
+  else if (K <= 24) { launch_grid_search<D, 24, NORM>(a, ws, wgs); launch_grid_wave<D, 24, NORM>(a, ws); }
+  else { launch_grid_search<D, 32, NORM>(a, ws, wgs); launch_grid_wave<D, 32, NORM>(a, ws); }
+}
+
+template <int D>
+static void run_d(const KnnArgs& a, int norm, const GridWs& ws, int wgs) {
+  const int tiles = (int)ceil_div(a.P1 > a.P2 ? a.P1 : a.P2, 256);
+  const dim3 bgrid((unsigned)tiles, (unsigned)a.N);
+  hipLaunchKernelGGL((grid_bin_kernel<D, false>), bgrid, dim3(256), 0, a.stream, a.p1, a.p2, a.P1, a.P2, a.K, ws,
+                     a.idxs, a.dists);
+  hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)a.N), dim3(kScanBlock), 0, a.stream, ws);
+  hipLaunchKernelGGL((grid_bin_kernel<D, true>), bgrid, dim3(256), 0, a.stream, a.p1, a.p2, a.P1, a.P2, a.K, ws,
+                     a.idxs, a.dists);
+  if (norm == 1) dispatch_grid_k<D, 1>(a, ws, wgs);
+  else dispatch_grid_k<D, 2>(a, ws, wgs);
+}
+
+int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
+  POINTOPS_REQUIRE(a.N < 65536, "knn_points_idx(grid): batch must be < 65536");
+  GridWs ws;
+  carve(&ws, (char*)workspace, a.N, a.P1, a.P2, a.K);
+  float c;
+  int B;
+  grid_tuning(a.K, &c, &B);
+  // histogram buffers (cell_count and blk_count are adjacent) start at zero
+  const size_t zero_bytes = (size_t)((char*)ws.cell_start - (char*)ws.cell_count);
+  if (hipMemsetAsync(ws.cell_count, 0, zero_bytes, a.stream) != hipSuccess) return check_launch("knn grid memset");
+  hipLaunchKernelGGL(grid_setup_kernel, dim3((unsigned)a.N), dim3(kSetupBlock), 0, a.stream, a.p2, a.l1, a.l2,
+                     a.P1, a.P2, a.D, c, B, ws);
+  hipLaunchKernelGGL(grid_prefix_kernel, dim3(1), dim3(64), 0, a.stream, ws, (int)a.N);
+  const int wgs = 256 * 32;  // one wave64 per workgroup, up to 32 waves per CU resident
+  switch (a.D) {
+    case 1: run_d<1>(a, norm, ws, wgs); break;
+    case 2: run_d<2>(a, norm, ws, wgs); break;
+    default: run_d<3>(a, norm, ws, wgs); break;
+  }
+  int rc = check_launch("knn_points_idx(grid)");
+  if (rc != POINTOPS_OK) return rc;
+  // exact fallback: whole-cloud scan for the queries the bound could not certify
+  KnnArgs fa = a;
+  fa.qlist = ws.fb2_list;
+  fa.qcount = ws.fb2_count;
+  launch_knn_bruteforce(fa, norm);
+  return check_launch("knn_points_idx(grid fallback)");
+}
+
+}  // namespace pointops
+
+extern "C" int pointops_knn_grid_fallback_counts(const void* workspace, int64_t N, int64_t P1, int64_t P2,
+                                                 int64_t K, int32_t* counts, void* stream) {
+  using namespace pointops;
+  POINTOPS_REQUIRE(workspace != nullptr && counts != nullptr && N > 0, "knn_grid_fallback_counts: bad arguments");
+  GridWs ws;
+  carve(&ws, (char*)workspace, N, P1, P2, (int)K);
+  if (hipMemcpyAsync(counts + N, ws.fb2_count, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice,
+                     (hipStream_t)stream) != hipSuccess)
+    return check_launch("knn_grid_fallback_counts");
+  if (hipMemcpyAsync(counts, ws.fb_count, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice,
+                     (hipStream_t)stream) != hipSuccess)
+    return check_launch("knn_grid_fallback_counts");
+  return POINTOPS_OK;
+}

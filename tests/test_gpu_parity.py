@@ -75,6 +75,62 @@ def test_knn_versions_agree(dev, oracle, version):
     assert np.array_equal(bits(r.dists.cpu().numpy()), bits(od))
 
 
+@pytest.mark.parametrize("name", sorted(n for n, c in cases.knn_cases().items() if c["p1"].shape[2] <= 3 and c["K"] <= 32))
+def test_knn_grid_version_matches_golden(dev, name):
+    """version=3 forces the exact grid-pruned search (+ brute-force fallback) on every small case."""
+    from pytorch3d_pointops_amd.functions import knn_points
+
+    g = load_golden("knn")
+    c = cases.knn_cases()[name]
+    r = knn_points(G(c["p1"], dev), G(c["p2"], dev), G(c["l1"], dev), G(c["l2"], dev), norm=c["norm"], K=c["K"],
+                   version=3)
+    assert np.array_equal(r.idx.cpu().numpy(), g[name + "/idx"].astype(np.int64))
+    assert np.array_equal(bits(r.dists.cpu().numpy()), bits(g[name + "/dists"]))
+
+
+def _grid_adversarial_cases():
+    c = {}
+    n = 3000
+    base = cases.cloud(1301, (2, n, 3))
+    c["disjoint_far"] = (base + np.float32(5.0), base, 8)           # every query outside p2's box -> fallback
+    c["clustered"] = ((cases.cloud(1302, (2, n, 3)) ** np.float32(6.0)).astype(np.float32),
+                      (cases.cloud(1303, (2, n, 3)) ** np.float32(6.0)).astype(np.float32), 16)
+    flat = cases.cloud(1304, (2, n, 3)); flat[..., 2] = np.float32(0.25)
+    c["planar"] = (flat, flat, 8)
+    line = cases.cloud(1305, (2, n, 3)); line[..., 1:] = np.float32(-1.0)
+    c["collinear"] = (line, line, 4)
+    same = np.zeros((2, n, 3), np.float32) + np.float32(0.7)
+    c["all_identical"] = (same, same, 5)
+    c["lattice_ties"] = (cases.lattice(1306, 2, n, levels=6), cases.lattice(1307, 2, n, levels=6), 16)
+    c["offset_1e3"] = (cases.cloud(1308, (2, n, 3)) + np.float32(1000.0), cases.cloud(1309, (2, n, 3)) + np.float32(1000.0), 8)
+    c["tiny_scale"] = (cases.cloud(1310, (2, n, 3)) * np.float32(1e-20), cases.cloud(1311, (2, n, 3)) * np.float32(1e-20), 8)
+    c["k1"] = (cases.cloud(1312, (2, n, 3)), cases.cloud(1313, (2, 2 * n, 3)), 1)
+    c["k32"] = (cases.cloud(1314, (2, n, 3)), cases.cloud(1315, (2, n, 3)), 32)
+    c["k11_l1"] = (cases.cloud(1316, (2, n, 3)), cases.cloud(1317, (2, n, 3)), 11)
+    c["d2"] = (cases.cloud(1318, (2, n, 2)), cases.cloud(1319, (2, n, 2)), 8)
+    c["d1"] = (cases.cloud(1320, (2, n, 1)), cases.cloud(1321, (2, n, 1)), 8)
+    return c
+
+
+@pytest.mark.parametrize("name", sorted(_grid_adversarial_cases()))
+def test_knn_grid_adversarial(dev, oracle, name):
+    """Grid search vs the CPU oracle on distributions that stress the bound / fallback logic,
+    with ragged lengths (one cloud shorter than K for the second query cloud)."""
+    from pytorch3d_pointops_amd.functions import knn_points
+
+    p1, p2, K = _grid_adversarial_cases()[name]
+    norm = 1 if name.endswith("_l1") else 2
+    l1 = np.array([p1.shape[1], p1.shape[1] // 3])
+    l2 = np.array([p2.shape[1], max(K - 2, 1)])
+    r = knn_points(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm=norm, K=K, version=3)
+    oi, od = oracle.knn_points_idx(p1, p2, l1, l2, norm, K)
+    assert np.array_equal(r.idx.cpu().numpy(), oi)
+    assert np.array_equal(bits(r.dists.cpu().numpy()), bits(od))
+    # and the brute-force family agrees too
+    r2 = knn_points(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm=norm, K=K, version=2)
+    assert torch.equal(r2.idx, r.idx) and torch.equal(r2.dists, r.dists)
+
+
 def test_knn_default_lengths_and_empty(dev, oracle):
     from pytorch3d_pointops_amd.functions import knn_points
 
