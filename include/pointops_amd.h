@@ -107,12 +107,15 @@ int pointops_ball_query(const float* p1, const float* p2, const int64_t* lengths
  *   points (N,P,D), lengths (N,), K (N,), start_idxs (N,), out idxs (N,max_K) int64
  *   padded with -1 beyond min(lengths[n], K[n]).  max_K = max(K) is passed by the
  *   host (the reference reads it with a host sync: sample_farthest_points.cu:132).
- *   min_dist_ws: device scratch of N*P floats (the running min-distance array).
+ *   workspace: pointops_fps_workspace_bytes(N, P, max_K) bytes of device scratch (running
+ *   min-distance array of the single-workgroup kernel + the per-iteration exchange slots of
+ *   the multi-workgroup cluster kernel).
  */
+size_t pointops_fps_workspace_bytes(int64_t N, int64_t P, int64_t max_K);
 int pointops_sample_farthest_points(const float* points, const int64_t* lengths,
                                     const int64_t* K, const int64_t* start_idxs, int64_t N,
                                     int64_t P, int64_t D, int64_t max_K, int64_t* idxs,
-                                    float* min_dist_ws, void* stream);
+                                    void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * packed <-> padded -- replace `_C.packed_to_padded` / `_C.padded_to_packed`

@@ -37,8 +37,9 @@ _SIGNATURES = {
                                             _i64, _int, _vp, _vp, _vp]),
     "pointops_ball_query": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _vp, _vp,
                                    _vp]),
+    "pointops_fps_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "pointops_sample_farthest_points": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp,
-                                               _vp]),
+                                               _sz, _vp]),
     "pointops_packed_to_padded": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "pointops_padded_to_packed": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "pointops_gather_neighbors": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
@@ -222,11 +223,12 @@ def sample_farthest_points(points, lengths, K, start_idxs):
     max_K = int(K.max().item()) if N > 0 else 0
     with torch.cuda.device(dev):
         idxs = torch.empty((N, max_K), dtype=torch.int64, device=dev)
-        ws = torch.empty((N, P), dtype=torch.float32, device=dev)
+        ws_bytes = _lib.pointops_fps_workspace_bytes(N, P, max_K)
+        ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
         _check(
             _lib.pointops_sample_farthest_points(points.data_ptr(), lengths.data_ptr(), K.data_ptr(),
                                                  start_idxs.data_ptr(), N, P, D, max_K,
-                                                 idxs.data_ptr(), ws.data_ptr(), _stream()),
+                                                 idxs.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
             "sample_farthest_points",
         )
     return idxs

@@ -142,20 +142,224 @@ __global__ __launch_bounds__(kFpsBlock) void fps_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// v2: register-resident clusters.  A cloud is split over G workgroups (G = ceil(P /
+// (PPT*1024)), up to one workgroup per CU); every lane keeps its PPT points AND their
+// running min-distances in VGPRs, so an iteration touches no memory except the
+// exchange: each workgroup reduces its local argmax, publishes it with ONE 64-bit
+// agent-scope atomicMax on the (cloud, iteration) slot -- key = distance bits << 32 |
+// ~index, so the maximum is the largest distance and, on ties, the LOWEST index, i.e.
+// std::max_element's first maximum -- then bumps the slot's arrival counter (release)
+// and polls it (relaxed agent-scope loads + s_sleep) until all G members arrived.
+// Slots are per iteration, zeroed by a memset node before the launch; only agent-scope
+// atomics ever touch them (cdna guide G16 "8-B agent atomics both sides"), the points
+// themselves are read-only input.  All workgroups of the grid are resident by
+// construction (grid <= number of CUs, one 1024-lane workgroup per CU), and every spin
+// is bounded.
+// ---------------------------------------------------------------------------
+constexpr unsigned kFpsSpinLimit = 1u << 24;
+
+template <int DT, int PPT>
+__global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
+    const float* __restrict__ points, const int64_t* __restrict__ lengths,
+    const int64_t* __restrict__ Ks, const int64_t* __restrict__ start_idxs, int N, int P, int max_K,
+    int G, int n_clusters, unsigned long long* __restrict__ slots, unsigned* __restrict__ arrive,
+    unsigned* __restrict__ timeout_flag, int64_t* __restrict__ idxs) {
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid / kWave;
+  const int cluster = blockIdx.x / G;
+  const int member = blockIdx.x - cluster * G;
+  __shared__ float s_val[kFpsWaves];
+  __shared__ int s_idx[kFpsWaves];
+  __shared__ int s_last;
+
+  for (int n = cluster; n < N; n += n_clusters) {
+    int len = (int)lengths[n];
+    if (len > P) len = P;
+    int64_t kn64 = Ks[n];
+    int kn = (int)(kn64 < (int64_t)len ? kn64 : (int64_t)len);
+    if (kn > max_K) kn = max_K;
+    if (kn < 0) kn = 0;
+    int64_t* __restrict__ out = idxs + (int64_t)n * max_K;
+    if (member == 0) {
+      for (int k = (kn > 0 ? kn : 0) + tid; k < max_K; k += kFpsBlock) out[k] = -1;
+    }
+    if (len <= 0 || kn <= 0) continue;
+
+    const float* __restrict__ pts = points + (int64_t)n * P * DT;
+    // this lane's points: p = member*PPT*1024 + i*1024 + tid  (ascending in i)
+    float px[PPT][DT];
+    float md[PPT];
+    const int base = member * (PPT * kFpsBlock) + tid;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int p = base + i * kFpsBlock;
+      const bool valid = p < len;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) px[i][d] = valid ? pts[(int64_t)p * DT + d] : 0.0f;
+      md[i] = valid ? FLT_MAX : -1.0f;  // -1: never the maximum
+    }
+    int last = (int)start_idxs[n];
+    if (last < 0 || last >= len) last = 0;
+    if (member == 0 && tid == 0) out[0] = last;
+    unsigned long long* __restrict__ cslots = slots + (int64_t)n * max_K;
+    unsigned* __restrict__ carrive = arrive + (int64_t)n * max_K;
+
+    for (int k = 1; k < kn; ++k) {
+      float c[DT];
+#pragma unroll
+      for (int d = 0; d < DT; ++d) c[d] = pts[(int64_t)last * DT + d];  // wave-uniform, read-only input
+      float best = -1.0f;
+      int besti = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        float acc;
+        {
+          const float diff = c[0] - px[i][0];
+          acc = diff * diff;
+        }
+#pragma unroll
+        for (int d = 1; d < DT; ++d) {
+          const float diff = c[d] - px[i][d];
+          acc = acc + diff * diff;
+        }
+        float m = md[i];
+        if (acc < m) m = acc;  // padded lanes keep -1 (acc >= 0 is never < -1)
+        md[i] = m;
+        if (m > best) {
+          best = m;
+          besti = base + i * kFpsBlock;
+        }
+      }
+#pragma unroll
+      for (int off = kWave / 2; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, kWave);
+        const int oi = __shfl_xor(besti, off, kWave);
+        argmax_combine(best, besti, ov, oi);
+      }
+      if (lane == 0) {
+        s_val[wave] = best;
+        s_idx[wave] = besti;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        float v = lane < kFpsWaves ? s_val[lane] : -2.0f;
+        int ix = lane < kFpsWaves ? s_idx[lane] : 0x7fffffff;
+#pragma unroll
+        for (int off = kFpsWaves / 2; off > 0; off >>= 1) {
+          const float ov = __shfl_xor(v, off, kWave);
+          const int oi = __shfl_xor(ix, off, kWave);
+          argmax_combine(v, ix, ov, oi);
+        }
+        if (lane == 0) {
+          int win = ix;
+          if (G > 1) {
+            const unsigned long long key =
+                (v >= 0.0f) ? (((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xffffffffu - (unsigned)ix))
+                            : 0ull;  // this member holds no valid point
+            __hip_atomic_fetch_max(cslots + k, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(carrive + k, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(carrive + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G) {
+              __builtin_amdgcn_s_sleep(2);
+              if (++spins > kFpsSpinLimit) {  // exit condition every wave reaches
+                __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+            const unsigned long long w = __hip_atomic_load(cslots + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            win = (int)(0xffffffffu - (unsigned)(w & 0xffffffffull));
+            if (win < 0 || win >= len) win = 0;  // only reachable after a timeout
+          }
+          s_last = win;
+          if (member == 0) out[k] = win;
+        }
+      }
+      __syncthreads();
+      last = s_last;
+    }
+    __syncthreads();  // s_last / s_val reuse by the next cloud of this cluster
+  }
+}
+
 }  // namespace pointops
 
 using namespace pointops;
 
+static int fps_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 64;
+  }
+  return cus;
+}
+
+extern "C" size_t pointops_fps_workspace_bytes(int64_t N, int64_t P, int64_t max_K) {
+  // v1 running min-distance array (N*P floats) + v2 exchange slots: (u64 slot + u32 arrival) per
+  // (cloud, iteration) + one timeout word
+  const size_t md = sizeof(float) * (size_t)(N * P);
+  const size_t ex = (sizeof(unsigned long long) + sizeof(unsigned)) * (size_t)(N * max_K) + 64;
+  return ((md + 255) & ~(size_t)255) + ex;
+}
+
 extern "C" int pointops_sample_farthest_points(const float* points, const int64_t* lengths,
                                                const int64_t* K, const int64_t* start_idxs,
                                                int64_t N, int64_t P, int64_t D, int64_t max_K,
-                                               int64_t* idxs, float* min_dist_ws, void* stream_) {
+                                               int64_t* idxs, void* workspace, size_t workspace_bytes,
+                                               void* stream_) {
   POINTOPS_REQUIRE(N >= 0 && P >= 0 && D >= 1 && max_K >= 0, "sample_farthest_points: bad sizes");
   POINTOPS_REQUIRE(P < (1LL << 31) && max_K < (1LL << 31) && D < (1LL << 16) && N < (1LL << 31),
                    "sample_farthest_points: sizes must fit int32");
   if (N == 0 || max_K == 0) return POINTOPS_OK;
-  POINTOPS_REQUIRE(P == 0 || min_dist_ws != nullptr, "sample_farthest_points: workspace is null");
+  POINTOPS_REQUIRE(workspace != nullptr && workspace_bytes >= pointops_fps_workspace_bytes(N, P, max_K),
+                   "sample_farthest_points: workspace of %zu bytes required",
+                   pointops_fps_workspace_bytes(N, P, max_K));
   hipStream_t stream = (hipStream_t)stream_;
+  float* min_dist_ws = (float*)workspace;
+  char* ex = (char*)workspace + ((sizeof(float) * (size_t)(N * P) + 255) & ~(size_t)255);
+  unsigned long long* slots = (unsigned long long*)ex;
+  unsigned* arrive = (unsigned*)(slots + (size_t)(N * max_K));
+  unsigned* timeout_flag = arrive + (size_t)(N * max_K);
+
+  // v2 (register-resident clusters) for D in {2,3}: up to PPT*1024 points per workgroup
+  const int cus = fps_num_cus();
+  if ((D == 3 || D == 2) && P >= 1) {
+    int ppt = P <= 8 * (int64_t)kFpsBlock * cus ? 8 : 16;
+    if (P <= 4 * (int64_t)kFpsBlock) ppt = 4;
+    const int64_t cap = (int64_t)ppt * kFpsBlock;
+    const int G = (int)ceil_div(P, cap);
+    if (G <= cus) {
+      int n_clusters = cus / G;
+      if (n_clusters > N) n_clusters = (int)N;
+      if (n_clusters < 1) n_clusters = 1;
+      if (G == 1) n_clusters = (int)N;  // no exchange: one independent workgroup per cloud
+      if (G > 1) {
+        const size_t zb = (sizeof(unsigned long long) + sizeof(unsigned)) * (size_t)(N * max_K) + 64;
+        if (hipMemsetAsync(ex, 0, zb, stream) != hipSuccess) return check_launch("fps(memset)");
+      }
+      const dim3 grid((unsigned)(n_clusters * G)), block(kFpsBlock);
+#define PO_LAUNCH_C(DT, PPT)                                                                         \
+  hipLaunchKernelGGL((fps_cluster_kernel<DT, PPT>), grid, block, 0, stream, points, lengths, K, start_idxs, \
+                     (int)N, (int)P, (int)max_K, G, n_clusters, slots, arrive, timeout_flag, idxs)
+      if (D == 3) {
+        if (ppt == 4) PO_LAUNCH_C(3, 4);
+        else if (ppt == 8) PO_LAUNCH_C(3, 8);
+        else PO_LAUNCH_C(3, 16);
+      } else {
+        if (ppt == 4) PO_LAUNCH_C(2, 4);
+        else if (ppt == 8) PO_LAUNCH_C(2, 8);
+        else PO_LAUNCH_C(2, 16);
+      }
+#undef PO_LAUNCH_C
+      return check_launch("sample_farthest_points");
+    }
+  }
   const dim3 grid((unsigned)N), block(kFpsBlock);
 #define PO_LAUNCH(DT)                                                                             \
   hipLaunchKernelGGL((fps_kernel<DT>), grid, block, 0, stream, points, lengths, K, start_idxs,     \

@@ -250,6 +250,23 @@ def test_sample_farthest_points(dev, oracle, name):
             assert torch.equal(ni, idx)  # examples/fps_on_pointclouds.py:153
 
 
+def test_fps_multi_workgroup_clusters(dev, oracle):
+    """Clouds larger than one workgroup's register capacity are split over a cluster of
+    workgroups that exchange their local argmax through per-iteration atomic slots; several
+    ragged clouds share the clusters (persistent loop)."""
+    from pytorch3d_pointops_amd import _C
+
+    for (N, P, D) in ((5, 10000, 3), (3, 40000, 3), (3, 9000, 2)):
+        pts = cases.cloud(1400 + P, (N, P, D))
+        pts[0, 100:200] = pts[0, 0:100]  # duplicates -> ties on the running min-distance
+        lengths = np.array([P, P // 2 + 7, 4097, 5, P - 1][:N])
+        K = np.array([64, 300, 17, 9, 128][:N])
+        start = np.array([0, 11, 4096, 4, P - 2][:N])
+        got = _C.sample_farthest_points(G(pts, dev), G(lengths, dev), G(K, dev), G(start, dev)).cpu().numpy()
+        want = oracle.sample_farthest_points(pts, lengths, K, start)
+        assert np.array_equal(got, want), (N, P, D)
+
+
 def test_fps_int_and_list_K_and_random_start(dev):
     from pytorch3d_pointops_amd.functions import sample_farthest_points
 
