@@ -76,6 +76,7 @@ struct GridWs {
   int* fb_list;       // N * P1
   int* fb2_count;     // N          queries the expanding search gave up on (whole-cloud scan)
   int* fb2_list;      // N * P1
+  unsigned* bbox;     // N * 8: ordered-uint keys of min x,y,z (atomicMin) and max x,y,z (atomicMax)
   int cell_cap;
 };
 
@@ -113,6 +114,64 @@ __device__ float edge_bisect(int c, float lo, float hi, float inv_h, int G) {
 // ---------------------------------------------------------------------------
 // pass 1: per-cloud grid parameters + edge tables
 // ---------------------------------------------------------------------------
+// pass 0: bounding boxes, all CUs.  fp32 min/max through order-preserving uint keys and
+// atomicMin / atomicMax (keys pre-set by grid_bbox_init_kernel).
+constexpr int kBboxBlock = 256;
+constexpr int kBboxPerThread = 16;
+
+__global__ void grid_bbox_init_kernel(unsigned* __restrict__ bbox, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N * 8) bbox[i] = ((i & 7) < 3) ? 0xffffffffu : 0u;  // [0..2] running min, [3..5] running max
+}
+
+__global__ __launch_bounds__(kBboxBlock) void grid_bbox_kernel(const float* __restrict__ p2,
+                                                             const int64_t* __restrict__ lengths2, int P2, int D,
+                                                             unsigned* __restrict__ bbox) {
+  const int n = blockIdx.y;
+  int len2 = (int)lengths2[n];
+  len2 = len2 < 0 ? 0 : (len2 > P2 ? P2 : len2);
+  const int j0 = blockIdx.x * (kBboxBlock * kBboxPerThread);
+  if (j0 >= len2) return;
+  float mn[3], mx[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    mn[d] = __builtin_inff();
+    mx[d] = -__builtin_inff();
+  }
+  const float* __restrict__ base = p2 + (int64_t)n * P2 * D;
+#pragma unroll 4
+  for (int r = 0; r < kBboxPerThread; ++r) {
+    const int j = j0 + r * kBboxBlock + threadIdx.x;
+    if (j < len2) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (d < D) {
+          const float v = base[(int64_t)j * D + d];
+          mn[d] = fminf(mn[d], v);
+          mx[d] = fmaxf(mx[d], v);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+      mn[d] = fminf(mn[d], __shfl_xor(mn[d], off, kWave));
+      mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, kWave));
+    }
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (d < D) {
+        atomicMin(bbox + n * 8 + d, fkey(mn[d]));
+        atomicMax(bbox + n * 8 + 3 + d, fkey(mx[d]));
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     const float* __restrict__ p2, const int64_t* __restrict__ lengths1,
     const int64_t* __restrict__ lengths2, int P1, int P2, int D, float c_target, int B, GridWs ws) {
@@ -122,49 +181,17 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
   len2 = len2 < 0 ? 0 : (len2 > P2 ? P2 : len2);
   int len1 = (int)lengths1[n];
   len1 = len1 < 0 ? 0 : (len1 > P1 ? P1 : len1);
-
-  float mn[3], mx[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    mn[d] = __builtin_inff();
-    mx[d] = -__builtin_inff();
-  }
-  const float* __restrict__ base = p2 + (int64_t)n * P2 * D;
-  for (int j = tid; j < len2; j += kSetupBlock) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      if (d < D) {
-        const float v = base[(int64_t)j * D + d];
-        mn[d] = fminf(mn[d], v);
-        mx[d] = fmaxf(mx[d], v);
-      }
-    }
-  }
-  __shared__ float s_mn[3][kSetupBlock / kWave], s_mx[3][kSetupBlock / kWave];
   __shared__ GridCloud s_g;
   __shared__ float s_hi[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-      mn[d] = fminf(mn[d], __shfl_xor(mn[d], off, kWave));
-      mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, kWave));
-    }
-    if ((tid & (kWave - 1)) == 0) {
-      s_mn[d][tid / kWave] = mn[d];
-      s_mx[d][tid / kWave] = mx[d];
-    }
-  }
-  __syncthreads();
   if (tid == 0) {
     GridCloud g;
     float lo[3], hi[3], e[3];
     bool finite = len2 > 0;
     for (int d = 0; d < 3; ++d) {
-      float a = __builtin_inff(), b = -__builtin_inff();
-      for (int w = 0; w < kSetupBlock / kWave; ++w) {
-        a = fminf(a, s_mn[d][w]);
-        b = fmaxf(b, s_mx[d][w]);
+      float a = 0.0f, b = 0.0f;
+      if (d < D && len2 > 0) {
+        a = funkey(ws.bbox[n * 8 + d]);
+        b = funkey(ws.bbox[n * 8 + 3 + d]);
       }
       if (d >= D) a = b = 0.0f;  // padded dimensions
       lo[d] = a;
@@ -400,6 +427,51 @@ __global__ __launch_bounds__(kScanBlock) void grid_scan_kernel(GridWs ws) {
 // distance ops run at the full VALU rate (an SGPR-sourced operand costs 1.5x:
 // profiles/r01_valu_microbench.txt).
 // ---------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------
+// register sorting networks on 64-bit (dist bits, idx) keys
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void key_ce(unsigned long long& a, unsigned long long& b, bool asc) {
+  // compare-exchange: afterwards a <= b when asc, a >= b otherwise.
+  // One 64-bit compare, one mask, four bit-selects (v_bfi_b32).  Written with an opaque mask
+  // because `sw ? b : a` / `sw ? a : b` are re-canonicalised by the compiler into umin/umax
+  // and lowered as TWO v_cmp_*_u64 (each with its own s_nop hazard pad) + 4 v_cndmask.
+  unsigned m = (asc ? (b < a) : (a < b)) ? 0xffffffffu : 0u;
+  asm volatile("" : "+v"(m));
+  const unsigned alo = (unsigned)a, ahi = (unsigned)(a >> 32), blo = (unsigned)b, bhi = (unsigned)(b >> 32);
+  const unsigned lo_lo = (m & blo) | (~m & alo), lo_hi = (m & bhi) | (~m & ahi);
+  const unsigned hi_lo = (m & alo) | (~m & blo), hi_hi = (m & ahi) | (~m & bhi);
+  a = ((unsigned long long)lo_hi << 32) | lo_lo;
+  b = ((unsigned long long)hi_hi << 32) | hi_lo;
+}
+
+template <int N>
+__device__ __forceinline__ void bitonic_sort(unsigned long long (&a)[N]) {  // ascending, N = 2^m
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int l = i ^ j;
+        if (l > i) key_ce(a[i], a[l], (i & k) == 0);
+      }
+    }
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void bitonic_merge(unsigned long long (&a)[N]) {  // bitonic -> ascending
+#pragma unroll
+  for (int j = N >> 1; j > 0; j >>= 1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int l = i ^ j;
+      if (l > i) key_ce(a[i], a[l], true);
+    }
+  }
+}
+
 template <int NORM>
 __device__ __forceinline__ float face_bound(float t) {  // t = fl(|q - face|) >= 0
   return NORM == 1 ? t : t * t;
@@ -415,12 +487,17 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
     const int* __restrict__ blk_start, const int* __restrict__ qlist, int* __restrict__ fb_count,
     int* __restrict__ fb_list, int cell_cap, int P1, int P2, int K, int N, int64_t* __restrict__ idxs,
     float* __restrict__ dists) {
-  // Per-lane candidate queues (KC >= 8): a candidate that beats the lane's (possibly stale)
-  // threshold is parked with one ds_write_b64; the sorted register list is only updated
-  // when some lane's queue is full, by ALL lanes together.  Without this almost every
-  // candidate makes the whole wave walk the ~100-instruction insert for one or two lanes.
-  constexpr bool kUseQueue = false;
-  constexpr int kQueueCap = 8;
+  // Per-lane candidate queues (KC >= 8).  Some lane of the wave wants almost every candidate
+  // (64 queries spread over the block), so a direct sorted insert makes the whole wave walk the
+  // ~100-instruction insert for one or two active lanes ~260 times per chunk.  Instead a
+  // candidate that beats the lane's (stale) threshold is parked with one ds_write_b64, and
+  // when some lane's queue is nearly full ALL lanes merge their queues into their lists with a
+  // branch-free network: bitonic-sort the queue, take min(list[i], queue[KC-1-i]) -- the KC
+  // smallest of the union as a bitonic sequence -- and bitonic-merge.  Cost per flush is fixed
+  // (~120 compare-exchanges at KC=16) and independent of how unevenly the lanes filled.
+  constexpr bool kUseQueue = KC >= 8 && (KC & (KC - 1)) == 0;
+  constexpr int kQueueCap = KC < 16 ? KC : 16;
+  constexpr int kSub = 4;  // candidates handled between two queue-full checks
   __shared__ unsigned long long s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
   __shared__ float4 s_tile[2][kGridWave];
   __shared__ int s_rowsrc[kMaxRows];  // first record of the row's run in `sorted`
@@ -511,12 +588,19 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
       unsigned thr = 0x7f800000u;  // distance bits a candidate must not exceed (stale between flushes)
       int qn = 0;                  // entries in this lane's queue
       auto flush = [&]() {
-        for (int t = 0; __any(t < qn); ++t) {
-          if (t < qn) {
-            const unsigned long long key = s_queue[t * kGridWave + lane];
-            if (key < top.key[KC - 1]) top.insert(key);
-          }
+        unsigned long long qk[kQueueCap];
+#pragma unroll
+        for (int t = 0; t < kQueueCap; ++t) {
+          const unsigned long long v = s_queue[t * kGridWave + lane];
+          qk[t] = t < qn ? v : TopKLex<KC>::kEmpty;
         }
+        bitonic_sort<kQueueCap>(qk);
+#pragma unroll
+        for (int t = 0; t < kQueueCap; ++t) {  // list slot KC-1-t meets queue entry t
+          const unsigned long long a = top.key[KC - 1 - t];
+          top.key[KC - 1 - t] = qk[t] < a ? qk[t] : a;
+        }
+        bitonic_merge<KC>(top.key);
         qn = 0;
         thr = top.worst_bits();
       };
@@ -532,35 +616,43 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
         nxt = fetch(t0 + kGridWave + lane, rhint);  // next tile's loads fly during this tile's scan
         __syncthreads();
         const int cnt = min(kGridWave, T - t0);
-#pragma unroll 4
-        for (int t = 0; t < cnt; ++t) {
-          const float4 c = s_tile[buf][t];  // wave-uniform LDS address: broadcast read
-          float d;
-          if (NORM == 1) {
-            d = __builtin_fabsf(qx - c.x);
-            if (D > 1) d = d + __builtin_fabsf(qy - c.y);
-            if (D > 2) d = d + __builtin_fabsf(qz - c.z);
-          } else {
-            const float dx = qx - c.x;
-            d = dx * dx;
-            if (D > 1) {
-              const float dy = qy - c.y;
-              d = d + dy * dy;
+        for (int tb = 0; tb < cnt; tb += kSub) {
+          float4 cc[kSub];
+#pragma unroll
+          for (int u = 0; u < kSub; ++u) cc[u] = s_tile[buf][(tb + u) & (kGridWave - 1)];  // broadcast reads
+#pragma unroll
+          for (int u = 0; u < kSub; ++u) {
+            const float4 c = cc[u];
+            float d;
+            if (NORM == 1) {
+              d = __builtin_fabsf(qx - c.x);
+              if (D > 1) d = d + __builtin_fabsf(qy - c.y);
+              if (D > 2) d = d + __builtin_fabsf(qz - c.z);
+            } else {
+              const float dx = qx - c.x;
+              d = dx * dx;
+              if (D > 1) {
+                const float dy = qy - c.y;
+                d = d + dy * dy;
+              }
+              if (D > 2) {
+                const float dz = qz - c.z;
+                d = d + dz * dz;
+              }
             }
-            if (D > 2) {
-              const float dz = qz - c.z;
-              d = d + dz * dz;
+            const bool live = tb + u < cnt;  // tail of the last tile
+            if (kUseQueue) {
+              if (live && __float_as_uint(d) <= thr) {
+                s_queue[qn * kGridWave + lane] = TopKLex<KC>::make(d, __float_as_int(c.w));
+                ++qn;
+              }
+            } else if (live && __float_as_uint(d) <= top.worst_bits()) {
+              const unsigned long long key = TopKLex<KC>::make(d, __float_as_int(c.w));
+              if (key < top.key[KC - 1]) top.insert(key);
             }
           }
           if (kUseQueue) {
-            if (__float_as_uint(d) <= thr) {
-              s_queue[qn * kGridWave + lane] = TopKLex<KC>::make(d, __float_as_int(c.w));
-              ++qn;
-            }
-            if (__any(qn == kQueueCap)) flush();
-          } else if (__float_as_uint(d) <= top.worst_bits()) {
-            const unsigned long long key = TopKLex<KC>::make(d, __float_as_int(c.w));
-            if (key < top.key[KC - 1]) top.insert(key);
+            if (__any(qn > kQueueCap - kSub)) flush();
           }
         }
         buf ^= 1;
@@ -771,6 +863,7 @@ static size_t carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, i
   w.fb_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.fb2_count = (int*)take(sizeof(int) * (size_t)N);
   w.fb2_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
+  w.bbox = (unsigned*)take(sizeof(unsigned) * (size_t)N * 8);
   if (ws) *ws = w;
   return off;
 }
@@ -832,6 +925,10 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
   // histogram buffers (cell_count and blk_count are adjacent) start at zero
   const size_t zero_bytes = (size_t)((char*)ws.cell_start - (char*)ws.cell_count);
   if (hipMemsetAsync(ws.cell_count, 0, zero_bytes, a.stream) != hipSuccess) return check_launch("knn grid memset");
+  hipLaunchKernelGGL(grid_bbox_init_kernel, dim3((unsigned)ceil_div(a.N * 8, 256)), dim3(256), 0, a.stream, ws.bbox,
+                     (int)a.N);
+  hipLaunchKernelGGL(grid_bbox_kernel, dim3((unsigned)ceil_div(a.P2, kBboxBlock * kBboxPerThread), (unsigned)a.N),
+                     dim3(kBboxBlock), 0, a.stream, a.p2, a.l2, a.P2, a.D, ws.bbox);
   hipLaunchKernelGGL(grid_setup_kernel, dim3((unsigned)a.N), dim3(kSetupBlock), 0, a.stream, a.p2, a.l1, a.l2,
                      a.P1, a.P2, a.D, c, B, ws);
   hipLaunchKernelGGL(grid_prefix_kernel, dim3(1), dim3(64), 0, a.stream, ws, (int)a.N);
