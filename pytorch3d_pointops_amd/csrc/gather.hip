@@ -42,7 +42,13 @@ __global__ __launch_bounds__(kGaBlock) void gather_backward_kernel(
   const int64_t j = idx[r];
   bool ok = j >= 0 && j < M;
   if (lengths != nullptr) ok = ok && (int64_t)k < lengths[n];
-  if (ok) atomicAdd(grad_x + (n * M + j) * U + u, grad_out[e]);
+  if (ok) {
+    // Adding +-0.0 to a sum that started at +0.0 never changes it, so zero gradients (every
+    // masked / padded row upstream) skip the atomic: padded rows all carry idx 0 and would
+    // otherwise serialise ~1e5 atomics on one address.
+    const float gv = grad_out[e];
+    if (gv != 0.0f) atomicAdd(grad_x + (n * M + j) * U + u, gv);
+  }
 }
 
 }  // namespace pointops

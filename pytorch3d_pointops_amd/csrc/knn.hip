@@ -185,10 +185,12 @@ int pointops_knn_check_version(int version, int64_t D, int64_t K) {
 }
 
 static int choose_version(int version, int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K) {
+  const bool grid_ok = pointops_knn_check_version(3, D, K) && P2 <= (1LL << 20);  // scan chunk table limit
+  if (version == 3 && !grid_ok) version = -1;
   if (version >= 0 && version <= 3 && pointops_knn_check_version(version, D, K)) return version;
   // auto: the grid only pays once the all-pairs scan is long enough to amortise its
   // (sort + scan) passes; below that the brute-force scan is latency-optimal.
-  if (pointops_knn_check_version(3, D, K) && P2 >= 4096 && P1 * P2 >= (1LL << 24)) return 3;
+  if (grid_ok && P2 >= 4096 && P1 * P2 >= (1LL << 24)) return 3;
   if (pointops_knn_check_version(2, D, K)) return 2;
   return 0;
 }

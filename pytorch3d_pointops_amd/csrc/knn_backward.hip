@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kBwdBlock) void knn_backward_kernel(
         if (NORM == 1) diff = g * ((av[d] > bv) ? 1.0f : -1.0f);
         else diff = 2.0f * g * (av[d] - bv);
         acc[d] = acc[d] + diff;
-        atomicAdd(g2 + d, -1.0f * diff);
+        if (diff != 0.0f) atomicAdd(g2 + d, -1.0f * diff);  // +-0 never changes a sum started at +0
       }
     }
 #pragma unroll
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kBwdBlock) void knn_backward_kernel(
         if (NORM == 1) diff = g * ((av > bv) ? 1.0f : -1.0f);
         else diff = 2.0f * g * (av - bv);
         acc = acc + diff;
-        atomicAdd(grad_p2 + ((int64_t)n * P2 + i2) * D + d, -1.0f * diff);
+        if (diff != 0.0f) atomicAdd(grad_p2 + ((int64_t)n * P2 + i2) * D + d, -1.0f * diff);
       }
       g1[d] = acc;
     }

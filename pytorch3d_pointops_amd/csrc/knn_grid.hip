@@ -77,6 +77,7 @@ struct GridWs {
   int* fb2_count;     // N          queries the expanding search gave up on (whole-cloud scan)
   int* fb2_list;      // N * P1
   unsigned* bbox;     // N * 8: ordered-uint keys of min x,y,z (atomicMin) and max x,y,z (atomicMax)
+  int* scan_partial;  // N * 2 * ceil(cell_cap / 4096): per-chunk sums / offsets of the two scans
   int cell_cap;
 };
 
@@ -360,73 +361,128 @@ __global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------
-// pass 3: exclusive scans (one workgroup per cloud); counts are reset to 0 so
-// they can serve as scatter cursors.
+// pass 3: exclusive scans of the cell and block histograms, chunked over all CUs:
+//   a) every (chunk, cloud) workgroup sums its 4096 counters -> partial[cloud][chunk]
+//   b) one workgroup per cloud turns the partials into chunk offsets (+ grand total)
+//   c) every (chunk, cloud) workgroup rescans its chunk from its offset, writes the starts
+//      and resets the counters to 0 so they can serve as scatter cursors.
+// (a single workgroup per cloud took 0.43 ms at 2e5 cells -- the K=1 / chamfer regime.)
 // ---------------------------------------------------------------------------
-__device__ void block_exclusive_scan_inplace(int* __restrict__ count, int* __restrict__ start, int n) {
-  __shared__ int s_part[kScanBlock / kWave];
-  __shared__ int s_total;
+constexpr int kScanChunk = 4096;  // counters per workgroup: 1024 lanes x int4
+
+__device__ __forceinline__ int block_sum_1024(int v, int* s_red) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  int t = lane < kScanBlock / kWave ? s_red[lane] : 0;
+#pragma unroll
+  for (int off = kScanBlock / kWave / 2; off > 0; off >>= 1) t += __shfl_xor(t, off, kWave);
+  __syncthreads();
+  return t;  // every lane of every wave holds the block total
+}
+
+// which: 0 = cells, 1 = blocks
+__device__ __forceinline__ void scan_arrays(const GridWs& ws, int n, int which, int*& count, int*& start,
+                                            int& len) {
+  const GridCloud g = ws.cloud[n];
+  count = (which == 0 ? ws.cell_count : ws.blk_count) + (int64_t)n * ws.cell_cap;
+  start = (which == 0 ? ws.cell_start : ws.blk_start) + (int64_t)n * (ws.cell_cap + 1);
+  len = g.use_grid ? (which == 0 ? g.ncell : g.nblock) : 0;
+}
+
+__global__ __launch_bounds__(kScanBlock) void grid_scan_partial_kernel(GridWs ws, int chunks) {
+  __shared__ int s_red[kScanBlock / kWave];
+  const int n = blockIdx.y, which = blockIdx.z, chunk = blockIdx.x;
+  int *count, *start, len;
+  scan_arrays(ws, n, which, count, start, len);
+  if (chunk * kScanChunk >= len) return;
+  int v = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = chunk * kScanChunk + threadIdx.x * 4 + r;
+    if (i < len) v += count[i];
+  }
+  const int tot = block_sum_1024(v, s_red);
+  if (threadIdx.x == 0) ws.scan_partial[((int64_t)n * 2 + which) * chunks + chunk] = tot;
+}
+
+__global__ __launch_bounds__(kScanBlock) void grid_scan_offsets_kernel(GridWs ws, int chunks) {
+  // chunks <= 1024 is guaranteed by the host (cell_cap <= 4M)
+  __shared__ int s_red[kScanBlock / kWave];
+  const int n = blockIdx.x, which = blockIdx.y;
+  int *count, *start, len;
+  scan_arrays(ws, n, which, count, start, len);
+  const int used = (len + kScanChunk - 1) / kScanChunk;
+  int* __restrict__ part = ws.scan_partial + ((int64_t)n * 2 + which) * chunks;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int per = (n + kScanBlock - 1) / kScanBlock;
-  const int b = tid * per;
-  const int e = (b + per < n) ? b + per : n;
-  int sum = 0;
-  for (int i = b; i < e; ++i) sum += count[i];
-  // inclusive wave scan of the per-thread sums
-  int inc = sum;
+  const int v = tid < used ? part[tid] : 0;
+  int inc = v;
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) {
-    const int v = __shfl_up(inc, off, kWave);
-    if (lane >= off) inc += v;
+    const int u = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += u;
   }
-  if (lane == kWave - 1) s_part[wave] = inc;
+  if (lane == kWave - 1) s_red[wave] = inc;
   __syncthreads();
   if (wave == 0) {
-    int v = lane < kScanBlock / kWave ? s_part[lane] : 0;
-    int winc = v;
+    const int w = lane < kScanBlock / kWave ? s_red[lane] : 0;
+    int winc = w;
 #pragma unroll
     for (int off = 1; off < kScanBlock / kWave; off <<= 1) {
       const int u = __shfl_up(winc, off, kWave);
       if (lane >= off) winc += u;
     }
-    if (lane < kScanBlock / kWave) s_part[lane] = winc - v;  // exclusive wave offsets
-    if (lane == kScanBlock / kWave - 1) s_total = winc;
+    if (lane < kScanBlock / kWave) s_red[lane] = winc - w;
   }
   __syncthreads();
-  int run = s_part[wave] + inc - sum;
-  for (int i = b; i < e; ++i) {
-    const int c = count[i];
-    start[i] = run;
-    run += c;
-    count[i] = 0;
+  if (tid < used) part[tid] = s_red[wave] + inc - v;  // exclusive chunk offset
+  if (len > 0 && tid == used - 1) start[len] = s_red[wave] + inc;  // grand total
+  if (len == 0 && tid == 0 && ws.cloud[n].use_grid) start[0] = 0;
+}
+
+__global__ __launch_bounds__(kScanBlock) void grid_scan_apply_kernel(GridWs ws, int chunks) {
+  __shared__ int s_red[kScanBlock / kWave];
+  const int n = blockIdx.y, which = blockIdx.z, chunk = blockIdx.x;
+  int *count, *start, len;
+  scan_arrays(ws, n, which, count, start, len);
+  if (chunk * kScanChunk >= len) return;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int i0 = chunk * kScanChunk + tid * 4;
+  int c[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = (i0 + r < len) ? count[i0 + r] : 0;
+  const int sum = c[0] + c[1] + c[2] + c[3];
+  int inc = sum;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int u = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += u;
   }
-  if (tid == 0) start[n] = s_total;
+  if (lane == kWave - 1) s_red[wave] = inc;
   __syncthreads();
+  if (wave == 0) {
+    const int w = lane < kScanBlock / kWave ? s_red[lane] : 0;
+    int winc = w;
+#pragma unroll
+    for (int off = 1; off < kScanBlock / kWave; off <<= 1) {
+      const int u = __shfl_up(winc, off, kWave);
+      if (lane >= off) winc += u;
+    }
+    if (lane < kScanBlock / kWave) s_red[lane] = winc - w;
+  }
+  __syncthreads();
+  int run = ws.scan_partial[((int64_t)n * 2 + which) * chunks + chunk] + s_red[wave] + inc - sum;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (i0 + r < len) {
+      start[i0 + r] = run;
+      run += c[r];
+      count[i0 + r] = 0;
+    }
+  }
 }
-
-__global__ __launch_bounds__(kScanBlock) void grid_scan_kernel(GridWs ws) {
-  const int n = blockIdx.x;
-  const GridCloud g = ws.cloud[n];
-  if (!g.use_grid) return;
-  block_exclusive_scan_inplace(ws.cell_count + (int64_t)n * ws.cell_cap,
-                               ws.cell_start + (int64_t)n * (ws.cell_cap + 1), g.ncell);
-  block_exclusive_scan_inplace(ws.blk_count + (int64_t)n * ws.cell_cap,
-                               ws.blk_start + (int64_t)n * (ws.cell_cap + 1), g.nblock);
-}
-
-// ---------------------------------------------------------------------------
-// pass 5: the search.  One wave64 per workgroup, persistent over (cloud, block) items.
-//
-// The candidate records of a block's region (block cells + one-cell halo) form a
-// FLAT STREAM: row (z,y) contributes the contiguous run cell_start[row,X0] ..
-// cell_start[row,X1+1] of the sorted array.  The stream is consumed in tiles of 64
-// records: lane t fetches record t of the tile with one coalesced 16-byte load
-// (issued one tile ahead, T14-style split of load and LDS write), parks it in LDS,
-// and the scan loop then reads record after record with a wave-uniform
-// ds_read_b128 -- a broadcast that delivers the candidate in VGPRs, so the eight
-// distance ops run at the full VALU rate (an SGPR-sourced operand costs 1.5x:
-// profiles/r01_valu_microbench.txt).
-// ---------------------------------------------------------------------------
 
 // ---------------------------------------------------------------------------
 // register sorting networks on 64-bit (dist bits, idx) keys
@@ -864,6 +920,7 @@ static size_t carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, i
   w.fb2_count = (int*)take(sizeof(int) * (size_t)N);
   w.fb2_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.bbox = (unsigned*)take(sizeof(unsigned) * (size_t)N * 8);
+  w.scan_partial = (int*)take(sizeof(int) * (size_t)N * 2 * (size_t)((cap + kScanChunk - 1) / kScanChunk));
   if (ws) *ws = w;
   return off;
 }
@@ -908,7 +965,12 @@ static void run_d(const KnnArgs& a, int norm, const GridWs& ws, int wgs) {
   const dim3 bgrid((unsigned)tiles, (unsigned)a.N);
   hipLaunchKernelGGL((grid_bin_kernel<D, false>), bgrid, dim3(256), 0, a.stream, a.p1, a.p2, a.P1, a.P2, a.K, ws,
                      a.idxs, a.dists);
-  hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)a.N), dim3(kScanBlock), 0, a.stream, ws);
+  const int chunks = (ws.cell_cap + kScanChunk - 1) / kScanChunk;
+  hipLaunchKernelGGL(grid_scan_partial_kernel, dim3((unsigned)chunks, (unsigned)a.N, 2), dim3(kScanBlock), 0, a.stream,
+                     ws, chunks);
+  hipLaunchKernelGGL(grid_scan_offsets_kernel, dim3((unsigned)a.N, 2), dim3(kScanBlock), 0, a.stream, ws, chunks);
+  hipLaunchKernelGGL(grid_scan_apply_kernel, dim3((unsigned)chunks, (unsigned)a.N, 2), dim3(kScanBlock), 0, a.stream,
+                     ws, chunks);
   hipLaunchKernelGGL((grid_bin_kernel<D, true>), bgrid, dim3(256), 0, a.stream, a.p1, a.p2, a.P1, a.P2, a.K, ws,
                      a.idxs, a.dists);
   if (norm == 1) dispatch_grid_k<D, 1>(a, ws, wgs);
@@ -917,6 +979,7 @@ static void run_d(const KnnArgs& a, int norm, const GridWs& ws, int wgs) {
 
 int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
   POINTOPS_REQUIRE(a.N < 65536, "knn_points_idx(grid): batch must be < 65536");
+  POINTOPS_REQUIRE(a.P2 <= (1 << 20), "knn_points_idx(grid): P2 must be <= 2^20");
   GridWs ws;
   carve(&ws, (char*)workspace, a.N, a.P1, a.P2, a.K);
   float c;
