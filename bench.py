@@ -94,7 +94,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # POINTOPS_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (1-GPU box rehearsal)
+    use_dist = world > 1 or os.environ.get("POINTOPS_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -118,7 +120,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -132,7 +134,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -145,8 +147,19 @@ def main():
     algo_bytes = B * (4 * D * (P + P) + P * K * 12)  # 452,984,832 B per launch
     achieved = algo_bytes / avg_kern_s / 1e9
 
+    # HBM-side bytes per step from the committed rocprofv3 PMC passes of this same command
+    # (tools/pmc_traffic.py; separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)
+    traffic, traffic_src = None, None
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tj) and args.version == -1:
+        try:
+            traffic = float(json.load(open(tj))["traffic_bytes_per_step"])
+            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
+        except Exception:  # noqa: BLE001
+            traffic = None
+
     result = {
-        "metric": "Mpoint-pairs/s knn_points B=32 N=65536 K=16",
+        "metric": "Mpoint-pairs/s (+ %HBM roofline) knn_points B=32 N=65536 K=16 @1/2/4/8 GPU",
         "value": value,
         "unit": "Mpoint-pairs/s",
         "n_gpus": world,
@@ -171,8 +184,11 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
-            "kernel": "knn scan (one launch per step)",
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "kernel": "knn_points_idx = grid build (bbox, histogram, scan, counting sort) + knn_grid_kernel "
+                      "(dominant, ~70 % of the step) + exact fallbacks; `achieved` prices the WHOLE op, "
+                      "HIP-event timed on the launch stream",
             "algorithmic_bytes_per_launch": algo_bytes,
             "avg_launch_ms": avg_kern_s * 1e3,
             "valu_frac_9ops_per_pair": pairs_per_step_rank * 9 / avg_kern_s / VALU_LANE_OPS,
@@ -186,9 +202,24 @@ def main():
         # the checker doubles as a parity probe of the benchmarked output
         gpu_idx = out[0][0, : args.cpu_sample_queries].cpu().numpy()
         result["cpu_baseline"]["idx_equal_on_sample"] = bool(np.array_equal(gpu_idx, cpu_idx[0]))
+    if use_dist:
+        # Outside the timed region: the path's one real exchange -- chamfer's batch reduction over
+        # clouds sharded across ranks = one RCCL all_gather of the per-cloud loss vectors.
+        try:
+            from pytorch3d_pointops_amd.sharded import sharded_chamfer_distance
+
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            loss, _ = sharded_chamfer_distance(p1, p2, B * world)
+            torch.cuda.synchronize()
+            result["sharded_chamfer"] = {"clouds_total": B * world, "loss": float(loss),
+                                         "first_call_ms": (time.perf_counter() - t1) * 1e3,
+                                         "collective": "one RCCL all_gather of (B/G,) fp32 per-cloud losses"}
+        except Exception as e:  # noqa: BLE001  (diagnostic only; never fails the bench line)
+            result["sharded_chamfer"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
