@@ -307,55 +307,111 @@ __device__ __forceinline__ void point_cells(const GridCloud& g, float x, float y
 }
 
 // ---------------------------------------------------------------------------
-// pass 2 / 4: histogram and counting-sort scatter (SCATTER = false / true)
+// pass 2 / 4: histogram and counting-sort scatter (SCATTER = false / true), for the
+// points of p2 by cell (IS_QUERY = false) and the queries of p1 by block (true).
+//
+// Scattered device-scope atomics run at only ~2e10/s chip-wide (they execute at the
+// memory side, one 64-byte request each), so a workgroup first bins its tile of
+// 1024 x 16 points in an LDS histogram (fast LDS atomics, which also hand every point
+// its rank inside the (tile, bin) group) and then touches each non-empty global
+// counter ONCE: count pass  global[bin] += n_tile ;  scatter pass  base = start[bin] +
+// atomicAdd(cursor[bin], n_tile), position = base + rank.  Clouds with more bins than
+// the LDS table holds (kBinLdsBins) use one global atomic per point.
 // ---------------------------------------------------------------------------
-template <int D, bool SCATTER>
-__global__ __launch_bounds__(256) void grid_bin_kernel(const float* __restrict__ p1,
-                                                       const float* __restrict__ p2, int P1, int P2, int K,
-                                                       GridWs ws, int64_t* __restrict__ idxs,
-                                                       float* __restrict__ dists) {
+constexpr int kBinBlock = 1024;
+constexpr int kBinPerThread = 16;
+constexpr int kBinTile = kBinBlock * kBinPerThread;
+constexpr int kBinLdsBins = 16384;  // 64 KiB of LDS
+
+template <int D, bool SCATTER, bool IS_QUERY>
+__global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __restrict__ pts, int P, int K, GridWs ws,
+                                                           int64_t* __restrict__ idxs, float* __restrict__ dists) {
+  __shared__ int s_hist[kBinLdsBins];
   const int n = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int tid = threadIdx.x;
   const GridCloud g = ws.cloud[n];  // wave-uniform
+  const int len = IS_QUERY ? g.len1 : g.len2;
+  const int nbins = IS_QUERY ? g.nblock : g.ncell;
   const int64_t cbase = (int64_t)n * ws.cell_cap;
-  if (g.use_grid && i < g.len2) {
-    float x, y, z;
-    load_point3<D>(p2 + ((int64_t)n * P2 + i) * D, x, y, z);
-    int cx, cy, cz;
-    point_cells(g, x, y, z, cx, cy, cz);
-    const int cell = (cz * g.G[1] + cy) * g.G[0] + cx;
-    if (!SCATTER) {
-      atomicAdd(ws.cell_count + cbase + cell, 1);
-    } else {
-      const int pos = ws.cell_start[(int64_t)n * (ws.cell_cap + 1) + cell] + atomicAdd(ws.cell_count + cbase + cell, 1);
-      ws.sorted[(int64_t)n * P2 + pos] = make_float4(x, y, z, __int_as_float(i));
-    }
-  }
-  if (i < P1) {
-    if (i >= g.len1) {
-      if (!SCATTER) {  // padded query row: zeros (knn_cpu.cpp:25-26)
-        int64_t* __restrict__ zi = idxs + ((int64_t)n * P1 + i) * K;
-        float* __restrict__ zd = dists + ((int64_t)n * P1 + i) * K;
+  int* __restrict__ gcount = (IS_QUERY ? ws.blk_count : ws.cell_count) + cbase;
+  const int* __restrict__ gstart = (IS_QUERY ? ws.blk_start : ws.cell_start) + (int64_t)n * (ws.cell_cap + 1);
+  const int i0 = blockIdx.x * kBinTile + tid;
+  if (blockIdx.x * kBinTile >= P) return;
+
+  if (IS_QUERY && !SCATTER) {
+    // rows that get no search: zeros for padded queries (knn_cpu.cpp:25-26); whole-cloud list
+    // when this cloud has no usable grid
+#pragma unroll 4
+    for (int r = 0; r < kBinPerThread; ++r) {
+      const int i = i0 + r * kBinBlock;
+      if (i < P && i >= g.len1) {
+        int64_t* __restrict__ zi = idxs + ((int64_t)n * P + i) * K;
+        float* __restrict__ zd = dists + ((int64_t)n * P + i) * K;
         for (int k = 0; k < K; ++k) {
           zi[k] = 0;
           zd[k] = 0.0f;
         }
+      } else if (i < g.len1 && !g.use_grid) {
+        const int pos = atomicAdd(ws.fb2_count + n, 1);
+        ws.fb2_list[(int64_t)n * P + pos] = i;
       }
-    } else if (g.use_grid) {
+    }
+  }
+  if (!g.use_grid || blockIdx.x * kBinTile >= len) return;
+
+  const bool use_lds = nbins <= kBinLdsBins;
+  if (use_lds) {
+    for (int b = tid; b < nbins; b += kBinBlock) s_hist[b] = 0;
+    __syncthreads();
+  }
+  int bin[kBinPerThread], rank[kBinPerThread];
+  float px[kBinPerThread], py[kBinPerThread], pz[kBinPerThread];
+#pragma unroll
+  for (int r = 0; r < kBinPerThread; ++r) {
+    const int i = i0 + r * kBinBlock;
+    bin[r] = -1;
+    rank[r] = 0;
+    if (i < len) {
       float x, y, z;
-      load_point3<D>(p1 + ((int64_t)n * P1 + i) * D, x, y, z);
+      load_point3<D>(pts + ((int64_t)n * P + i) * D, x, y, z);
       int cx, cy, cz;
       point_cells(g, x, y, z, cx, cy, cz);
-      const int b = ((cz / g.B) * g.NB[1] + (cy / g.B)) * g.NB[0] + (cx / g.B);
-      if (!SCATTER) {
-        atomicAdd(ws.blk_count + cbase + b, 1);
-      } else {
-        const int pos = ws.blk_start[(int64_t)n * (ws.cell_cap + 1) + b] + atomicAdd(ws.blk_count + cbase + b, 1);
-        ws.qlist[(int64_t)n * P1 + pos] = i;
+      bin[r] = IS_QUERY ? ((cz / g.B) * g.NB[1] + (cy / g.B)) * g.NB[0] + (cx / g.B)
+                        : (cz * g.G[1] + cy) * g.G[0] + cx;
+      if (SCATTER && !IS_QUERY) {
+        px[r] = x;
+        py[r] = y;
+        pz[r] = z;
       }
-    } else if (!SCATTER) {  // no usable grid for this cloud: whole-cloud scan
-      const int pos = atomicAdd(ws.fb2_count + n, 1);
-      ws.fb2_list[(int64_t)n * P1 + pos] = i;
+      if (use_lds) {
+        rank[r] = atomicAdd(&s_hist[bin[r]], 1);  // LDS atomic: rank inside (tile, bin)
+      } else if (!SCATTER) {
+        atomicAdd(gcount + bin[r], 1);
+      } else {
+        rank[r] = gstart[bin[r]] + atomicAdd(gcount + bin[r], 1);  // final position
+      }
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int b = tid; b < nbins; b += kBinBlock) {
+      const int c = s_hist[b];
+      if (c > 0) {
+        if (!SCATTER) atomicAdd(gcount + b, c);
+        else s_hist[b] = gstart[b] + atomicAdd(gcount + b, c);  // base of this tile's group
+      }
+    }
+    if (SCATTER) __syncthreads();
+  }
+  if (SCATTER) {
+#pragma unroll
+    for (int r = 0; r < kBinPerThread; ++r) {
+      if (bin[r] >= 0) {
+        const int i = i0 + r * kBinBlock;
+        const int pos = use_lds ? s_hist[bin[r]] + rank[r] : rank[r];
+        if (IS_QUERY) ws.qlist[(int64_t)n * P + pos] = i;
+        else ws.sorted[(int64_t)n * P + pos] = make_float4(px[r], py[r], pz[r], __int_as_float(i));
+      }
     }
   }
 }
@@ -961,18 +1017,21 @@ static void dispatch_grid_k(const KnnArgs& a, const GridWs& ws, int wgs) {
 
 template <int D>
 static void run_d(const KnnArgs& a, int norm, const GridWs& ws, int wgs) {
-  const int tiles = (int)ceil_div(a.P1 > a.P2 ? a.P1 : a.P2, 256);
-  const dim3 bgrid((unsigned)tiles, (unsigned)a.N);
-  hipLaunchKernelGGL((grid_bin_kernel<D, false>), bgrid, dim3(256), 0, a.stream, a.p1, a.p2, a.P1, a.P2, a.K, ws,
-                     a.idxs, a.dists);
+  const dim3 g2((unsigned)ceil_div(a.P2, kBinTile), (unsigned)a.N), g1((unsigned)ceil_div(a.P1, kBinTile), (unsigned)a.N);
+  hipLaunchKernelGGL((grid_bin_kernel<D, false, false>), g2, dim3(kBinBlock), 0, a.stream, a.p2, a.P2, a.K, ws, a.idxs,
+                     a.dists);
+  hipLaunchKernelGGL((grid_bin_kernel<D, false, true>), g1, dim3(kBinBlock), 0, a.stream, a.p1, a.P1, a.K, ws, a.idxs,
+                     a.dists);
   const int chunks = (ws.cell_cap + kScanChunk - 1) / kScanChunk;
   hipLaunchKernelGGL(grid_scan_partial_kernel, dim3((unsigned)chunks, (unsigned)a.N, 2), dim3(kScanBlock), 0, a.stream,
                      ws, chunks);
   hipLaunchKernelGGL(grid_scan_offsets_kernel, dim3((unsigned)a.N, 2), dim3(kScanBlock), 0, a.stream, ws, chunks);
   hipLaunchKernelGGL(grid_scan_apply_kernel, dim3((unsigned)chunks, (unsigned)a.N, 2), dim3(kScanBlock), 0, a.stream,
                      ws, chunks);
-  hipLaunchKernelGGL((grid_bin_kernel<D, true>), bgrid, dim3(256), 0, a.stream, a.p1, a.p2, a.P1, a.P2, a.K, ws,
-                     a.idxs, a.dists);
+  hipLaunchKernelGGL((grid_bin_kernel<D, true, false>), g2, dim3(kBinBlock), 0, a.stream, a.p2, a.P2, a.K, ws, a.idxs,
+                     a.dists);
+  hipLaunchKernelGGL((grid_bin_kernel<D, true, true>), g1, dim3(kBinBlock), 0, a.stream, a.p1, a.P1, a.K, ws, a.idxs,
+                     a.dists);
   if (norm == 1) dispatch_grid_k<D, 1>(a, ws, wgs);
   else dispatch_grid_k<D, 2>(a, ws, wgs);
 }
