@@ -279,14 +279,19 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
   }
 }
 
-// prefix of blocks over clouds (work decode of the persistent kernel)
+// Work decode of the persistent search kernel.  The unit of work is one CHUNK of <= 64 queries
+// of one block, so that a block holding thousands of queries (dense cluster in a uniform grid)
+// is spread over many workgroups instead of being walked chunk after chunk by one wave.
+// Chunk k of block b lives in slot  (blk_start[b] >> 6) + b + k : the slot ranges of
+// consecutive blocks never overlap (floor((s+q)/64) - floor(s/64) + 1 >= ceil(q/64)) and a
+// cloud needs at most len1/64 + nblock + 1 slots; empty slots are skipped.
 __global__ void grid_prefix_kernel(GridWs ws, int N) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int acc = 0;
     ws.block_prefix[0] = 0;
     for (int n = 0; n < N; ++n) {
       const GridCloud g = ws.cloud[n];
-      acc += g.use_grid ? g.nblock : 0;
+      acc += g.use_grid ? (g.len1 / kGridWave + g.nblock + 1) : 0;
       ws.block_prefix[n + 1] = acc;
     }
   }
@@ -626,12 +631,21 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
       else hi_n = mid;
     }
     const int n = lo_n;
-    const int b = item - block_prefix[n];
-    const int* __restrict__ bstart = blk_start + (int64_t)n * (cell_cap + 1);
-    const int qs = bstart[b], qe = bstart[b + 1];
-    if (qs == qe) continue;
-
+    const int slot = item - block_prefix[n];
     const GridCloud g = clouds[n];
+    const int* __restrict__ bstart = blk_start + (int64_t)n * (cell_cap + 1);
+    // block of this slot: largest b with (bstart[b] >> 6) + b <= slot  (monotone in b)
+    int lo_b = 0, hi_b = g.nblock;
+    while (hi_b - lo_b > 1) {
+      const int mid = (lo_b + hi_b) >> 1;
+      if ((bstart[mid] >> 6) + mid <= slot) lo_b = mid;
+      else hi_b = mid;
+    }
+    const int b = lo_b;
+    const int qe = bstart[b + 1];
+    const int qs = bstart[b] + kGridWave * (slot - ((bstart[b] >> 6) + b));  // first query of this chunk
+    if (qs >= qe) continue;  // empty slot
+
     const int bx = b % g.NB[0], by = (b / g.NB[0]) % g.NB[1], bz = b / (g.NB[0] * g.NB[1]);
     const int X0 = max(bx * g.B - 1, 0), X1 = min(bx * g.B + g.B, g.G[0] - 1);
     const int Y0 = max(by * g.B - 1, 0), Y1 = min(by * g.B + g.B, g.G[1] - 1);
@@ -689,7 +703,8 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
       return v;
     };
 
-    for (int c0 = qs; c0 < qe; c0 += kGridWave) {
+    {
+      const int c0 = qs;
       const bool active = c0 + lane < qe;
       const int qi = active ? ql[c0 + lane] : 0;
       float qx = 0.0f, qy = 0.0f, qz = 0.0f;

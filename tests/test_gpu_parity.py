@@ -109,6 +109,12 @@ def _grid_adversarial_cases():
     c["k11_l1"] = (cases.cloud(1316, (2, n, 3)), cases.cloud(1317, (2, n, 3)), 11)
     c["d2"] = (cases.cloud(1318, (2, n, 2)), cases.cloud(1319, (2, n, 2)), 8)
     c["d1"] = (cases.cloud(1320, (2, n, 1)), cases.cloud(1321, (2, n, 1)), 8)
+    # half of each cloud inside a tiny cluster: a few grid blocks hold thousands of queries and
+    # candidates (the chunk-level work split keeps this from serialising on one wave)
+    m = 20000
+    a = cases.cloud(1322, (2, m, 3)); a[:, : m // 2] = a[:, : m // 2] * np.float32(1e-3) + np.float32(0.5)
+    b = cases.cloud(1323, (2, m, 3)); b[:, : m // 2] = b[:, : m // 2] * np.float32(1e-3) + np.float32(0.5)
+    c["half_in_cluster"] = (a, b, 8)
     return c
 
 
