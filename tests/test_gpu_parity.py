@@ -232,6 +232,22 @@ def test_ball_query(dev, oracle, name):
     assert close(p2.grad.cpu().numpy(), g[name + "/grad_p2"])
 
 
+@pytest.mark.parametrize("radius,K", [(0.05, 16), (0.3, 8), (0.12, 64)])
+def test_ball_query_larger_clouds(dev, oracle, radius, K):
+    """Larger clouds: sparse balls (queries that never fill scan everything), dense balls (early
+    exit), K = 64, ragged lengths."""
+    from pytorch3d_pointops_amd import _C
+
+    p1 = cases.cloud(1501, (2, 3000, 3))
+    p2 = cases.cloud(1502, (2, 20000, 3))
+    l1 = np.array([3000, 1234])
+    l2 = np.array([20000, 6000])
+    idx, d = _C.ball_query(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), K, radius)
+    oi, od = oracle.ball_query(p1, p2, l1, l2, K, radius)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(bits(d.cpu().numpy()), bits(od))
+
+
 # ------------------------------------------------------------------ FPS
 @pytest.mark.parametrize("name", sorted(cases.fps_cases()))
 def test_sample_farthest_points(dev, oracle, name):
