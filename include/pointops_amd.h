@@ -160,6 +160,30 @@ int pointops_gather_neighbors_backward(const float* grad_out, const int64_t* idx
 int pointops_chamfer_reduce(const float* dists, const int64_t* lengths, const float* weights,
                             int64_t N, int64_t P, int mean, float* out, void* stream);
 
+/*
+ * Fused single-direction chamfer terms for K = 1 and point_reduction in {"sum","mean"} --
+ * the tail of `_chamfer_distance_single_direction` after its knn_points call
+ * (reference: functions/chamfer.py:135-185) including the per-feature cosine loss:
+ *   out[0][n]   = w_n / den_n * sum_{i < xlen_n} dists[n,i]
+ *   out[1+f][n] = w_n / den_n * sum_{i < xlen_n} (1 - |cos(xf_f[n,i], yf_f[n, idx[n,i]])|)   (|.| if abs_cosine)
+ * with den_n = max(xlen_n, 1) for "mean", 1 for "sum"; cos uses F.cosine_similarity's eps = 1e-6.
+ * x_feats / y_feats / C are HOST arrays of F (<= 4) device pointers / channel counts (<= 16).
+ * The backward is closed-form: grad_x, grad_x_feats written densely, grad_y / grad_y_feats are
+ * zero-filled then scatter-added with fp32 atomics.  grad_out is (1+F, N).
+ */
+size_t pointops_chamfer_workspace_bytes(int64_t N, int64_t P1);
+int pointops_chamfer_forward(const float* dists, const int64_t* idx, const int64_t* x_lengths,
+                             const int64_t* y_lengths, const float* weights, int64_t N, int64_t P1,
+                             int64_t P2, int F, const float* const* x_feats, const float* const* y_feats,
+                             const int64_t* C, int abs_cosine, int mean, float* out, void* workspace,
+                             size_t workspace_bytes, void* stream);
+int pointops_chamfer_backward(const float* x, const float* y, const int64_t* idx, const int64_t* x_lengths,
+                              const int64_t* y_lengths, const float* weights, const float* grad_out,
+                              int64_t N, int64_t P1, int64_t P2, int64_t D, int norm, int F,
+                              const float* const* x_feats, const float* const* y_feats, const int64_t* C,
+                              int abs_cosine, int mean, float* grad_x, float* grad_y,
+                              float* const* grad_x_feats, float* const* grad_y_feats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

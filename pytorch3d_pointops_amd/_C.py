@@ -46,6 +46,11 @@ _SIGNATURES = {
     "pointops_gather_neighbors_backward": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp,
                                                   _vp]),
     "pointops_chamfer_reduce": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),
+    "pointops_chamfer_workspace_bytes": (_sz, [_i64, _i64]),
+    "pointops_chamfer_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _int,
+                                        _int, _vp, _vp, _sz, _vp]),
+    "pointops_chamfer_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int,
+                                         _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -318,3 +323,64 @@ def chamfer_reduce(dists, lengths, weights, mean: bool):
             "chamfer_reduce",
         )
     return out
+
+
+# --- fused single-direction chamfer terms (functions/chamfer.py:135-185) --------------------
+CHAMFER_MAX_FEATURES = 4
+CHAMFER_MAX_CHANNELS = 16
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def chamfer_forward(dists, idx, x_lengths, y_lengths, weights, x_feats, y_feats, abs_cosine: bool, mean: bool):
+    """dists (N,P1) fp32 and idx (N,P1) int64 of the K=1 search -> out (1+F, N): row 0 the point term,
+    row 1+f the cosine term of feature f, each already weighted and (for "mean") length-normalised."""
+    dev = _require_gpu(dists, idx, x_lengths, y_lengths)
+    N, P1 = dists.shape
+    F = len(x_feats)
+    P2 = y_feats[0].shape[1] if F else 0
+    C = (ctypes.c_int64 * max(F, 1))(*[int(t.shape[2]) for t in x_feats])
+    with torch.cuda.device(dev):
+        out = torch.empty((1 + F, N), dtype=torch.float32, device=dev)
+        ws_bytes = _lib.pointops_chamfer_workspace_bytes(N, P1)
+        ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
+        _check(
+            _lib.pointops_chamfer_forward(dists.data_ptr(), idx.data_ptr(), x_lengths.data_ptr(),
+                                          y_lengths.data_ptr(),
+                                          weights.data_ptr() if weights is not None else None, N, P1, P2, F,
+                                          _ptr_array(x_feats), _ptr_array(y_feats), C, int(bool(abs_cosine)),
+                                          int(bool(mean)), out.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
+            "chamfer_forward",
+        )
+    return out
+
+
+def chamfer_backward(x, y, idx, x_lengths, y_lengths, weights, grad_out, norm: int, x_feats, y_feats,
+                     abs_cosine: bool, mean: bool):
+    """Closed-form gradients of chamfer_forward's outputs: returns (grad_x, grad_y, [grad_x_feat], [grad_y_feat])."""
+    dev = _require_gpu(x, y, idx, grad_out)
+    N, P1, D = x.shape
+    P2 = y.shape[1]
+    F = len(x_feats)
+    C = (ctypes.c_int64 * max(F, 1))(*[int(t.shape[2]) for t in x_feats])
+    with torch.cuda.device(dev):
+        grad_x = torch.empty_like(x)
+        grad_y = torch.empty_like(y)
+        gxf = [torch.empty_like(t) for t in x_feats]
+        gyf = [torch.empty_like(t) for t in y_feats]
+        _check(
+            _lib.pointops_chamfer_backward(x.data_ptr(), y.data_ptr(), idx.data_ptr(), x_lengths.data_ptr(),
+                                           y_lengths.data_ptr(),
+                                           weights.data_ptr() if weights is not None else None,
+                                           grad_out.data_ptr(), N, P1, P2, D, int(norm), F, _ptr_array(x_feats),
+                                           _ptr_array(y_feats), C, int(bool(abs_cosine)), int(bool(mean)),
+                                           grad_x.data_ptr(), grad_y.data_ptr(), _ptr_array(gxf), _ptr_array(gyf),
+                                           _stream()),
+            "chamfer_backward",
+        )
+    return grad_x, grad_y, gxf, gyf

@@ -106,6 +106,59 @@ class _masked_point_reduce(Function):
         return scale[:, None] * mask, None, None, None
 
 
+class _chamfer_direction(Function):
+    """One chamfer direction for point_reduction in {"sum","mean"}: K=1 grid search + ONE fused
+    kernel for the masked / weighted / normalised per-cloud sums of the point term and of every
+    cosine feature term, with a closed-form fused backward (device half: csrc/chamfer.hip).
+    Returns a (1+F, N) tensor: row 0 the point term, row 1+f feature f."""
+
+    @staticmethod
+    def forward(ctx, x, y, x_lengths, y_lengths, weights, norm, mean, abs_cosine, *feats):
+        F_ = len(feats) // 2
+        x_feats = [f.contiguous() for f in feats[:F_]]
+        y_feats = [f.contiguous() for f in feats[F_:]]
+        x, y = x.contiguous(), y.contiguous()
+        idx, dists = _C.knn_points_idx(x, y, x_lengths, y_lengths, norm, 1, -1)
+        out = _C.chamfer_forward(dists.view(dists.shape[0], dists.shape[1]), idx.view(idx.shape[0], idx.shape[1]),
+                                 x_lengths, y_lengths, weights, x_feats, y_feats, abs_cosine, mean)
+        ctx.save_for_backward(x, y, idx, x_lengths, y_lengths,
+                              weights if weights is not None else x.new_empty(0), *x_feats, *y_feats)
+        ctx.has_w = weights is not None
+        ctx.cfg = (int(norm), bool(mean), bool(abs_cosine), F_)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        norm, mean, abs_cosine, F_ = ctx.cfg
+        x, y, idx, xl, yl, w = ctx.saved_tensors[:6]
+        x_feats = list(ctx.saved_tensors[6:6 + F_])
+        y_feats = list(ctx.saved_tensors[6 + F_:6 + 2 * F_])
+        gx, gy, gxf, gyf = _C.chamfer_backward(x, y, idx.view(idx.shape[0], idx.shape[1]), xl, yl,
+                                               w if ctx.has_w else None, grad_out.contiguous().float(), norm,
+                                               x_feats, y_feats, abs_cosine, mean)
+        return (gx, gy, None, None, None, None, None, None, *gxf, *gyf)
+
+
+def _fused_direction_ok(x, y, x_features, y_features, feature_names, return_features, point_reduction):
+    if point_reduction not in ("sum", "mean"):
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32):
+        return False
+    if return_features:
+        if len(feature_names) > _C.CHAMFER_MAX_FEATURES:
+            return False
+        for name in feature_names:
+            a, b = x_features[name], y_features[name]
+            if a.dtype != torch.float32 or b.dtype != torch.float32 or a.ndim != 3 or b.ndim != 3:
+                return False
+            if a.shape[2] != b.shape[2] or a.shape[2] > _C.CHAMFER_MAX_CHANNELS:
+                return False
+            if a.shape[:2] != x.shape[:2] or b.shape[:2] != y.shape[:2]:
+                return False
+    return True
+
+
 def _chamfer_distance_single_direction(
     x,
     y,
@@ -152,6 +205,14 @@ def _chamfer_distance_single_direction(
                 zero = zero[:, None].expand(N, P1)
             zf = {name: zero for name in feature_names} if return_features else None
             return zero, zf
+
+    if _fused_direction_ok(x, y, x_features, y_features, feature_names, return_features, point_reduction):
+        names = list(feature_names) if return_features else []
+        feats = [x_features[k] for k in names] + [y_features[k] for k in names]
+        out = _chamfer_direction.apply(x, y, x_lengths, y_lengths,
+                                       weights.to(torch.float32) if weights is not None else None, norm,
+                                       point_reduction == "mean", abs_cosine, *feats)
+        return out[0], ({k: out[1 + i] for i, k in enumerate(names)} if return_features else None)
 
     x_nn = knn_points(x, y, lengths1=x_lengths, lengths2=y_lengths, norm=norm, K=1)
     cham_x = x_nn.dists[..., 0]  # (N, P1); rows >= x_lengths are already 0 (kernel padding)
