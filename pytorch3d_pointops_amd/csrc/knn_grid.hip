@@ -39,6 +39,7 @@
 // of every unvisited point is >= LB, and `kth < LB` (strict) also rules out ties.
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "knn_common.h"
 #include "knn_grid.h"
@@ -562,19 +563,36 @@ __device__ __forceinline__ void key_ce(unsigned long long& a, unsigned long long
   b = ((unsigned long long)hi_hi << 32) | hi_lo;
 }
 
+// Sorting networks for the queue (ascending).  16 inputs: the 60-comparator, 10-layer network
+// (optimal size; checked exhaustively with the 0-1 principle, tools/verify_sort_networks.py);
+// 8 inputs: Batcher's odd-even merge sort, 19 comparators (optimal).
 template <int N>
-__device__ __forceinline__ void bitonic_sort(unsigned long long (&a)[N]) {  // ascending, N = 2^m
+struct SortNet {  // other sizes are never executed (the queue exists only for KC >= 8)
+  static constexpr int kSize = 0;
+  static constexpr unsigned char kA[1] = {0};
+  static constexpr unsigned char kB[1] = {0};
+};
+template <>
+struct SortNet<16> {
+  static constexpr int kSize = 60;
+  static constexpr unsigned char kA[60] = {0, 1, 2,  3,  4, 5, 7,  9,  0, 1, 2, 3, 6,  8,  10, 11, 0, 2, 4, 6,
+                                           7, 10, 12, 14, 0, 1, 4,  5,  6, 8, 12, 13, 1, 3,  4,  5,  8, 9, 13, 1,
+                                           2, 5,  7,  9,  11, 2, 3, 9,  11, 3, 6, 7,  10, 3, 5,  7,  9,  11, 6, 8};
+  static constexpr unsigned char kB[60] = {13, 12, 15, 14, 8,  6,  11, 10, 5,  7,  9,  4,  13, 14, 15, 12, 1, 3, 5, 8,
+                                           9,  11, 13, 15, 2,  3,  10, 11, 7,  9,  14, 15, 2,  12, 6,  7,  10, 11, 14, 4,
+                                           6,  8,  10, 13, 14, 4,  6,  12, 13, 5,  8,  9,  12, 4,  6,  8,  10, 12, 7, 9};
+};
+template <>
+struct SortNet<8> {
+  static constexpr int kSize = 19;
+  static constexpr unsigned char kA[19] = {0, 2, 0, 1, 1, 4, 6, 4, 5, 5, 0, 2, 2, 1, 3, 3, 1, 3, 5};
+  static constexpr unsigned char kB[19] = {1, 3, 2, 3, 2, 5, 7, 6, 7, 6, 4, 6, 4, 5, 7, 5, 2, 4, 6};
+};
+
+template <int N>
+__device__ __forceinline__ void bitonic_sort(unsigned long long (&a)[N]) {  // ascending
 #pragma unroll
-  for (int k = 2; k <= N; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        const int l = i ^ j;
-        if (l > i) key_ce(a[i], a[l], (i & k) == 0);
-      }
-    }
-  }
+  for (int i = 0; i < SortNet<N>::kSize; ++i) key_ce(a[SortNet<N>::kA[i]], a[SortNet<N>::kB[i]], true);
 }
 
 template <int N>
@@ -950,7 +968,12 @@ static int grid_kc(int K) { return K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8
 
 static void grid_tuning(int K, float* c_target, int* B) {
   // the search keeps the KC >= K best and certifies the KC-th, so size the cells for KC
-  float c = 0.5f * (float)grid_kc(K);
+  // points per cell: measured optimum at B=32, N=65536 (profiles/r01_grid_tuning.txt): 0.4 KC for the
+  // queue/network variants (KC >= 8; fewer candidates per region at ~0.6 % uncertified queries),
+  // 0.5 KC for the direct-insert variants
+  const int kc = grid_kc(K);
+  float c = (kc >= 8 ? 0.4f : 0.5f) * (float)kc;
+  if (const char* e = getenv("POINTOPS_GRID_C_SCALE")) c *= (float)atof(e);  // tuning experiments only
   if (c < 1.0f) c = 1.0f;
   int b = (int)lround(cbrt(64.0 / (double)c));  // ~64 queries (one wave) per block
   if (b < 1) b = 1;
