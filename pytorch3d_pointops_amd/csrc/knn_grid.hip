@@ -712,7 +712,10 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
 
     // record t of the flat stream -> its address (per lane); `rh` = a row at or before t's row
     auto fetch = [&](int t, int rh) -> float4 {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      // beyond the stream: NaN coordinates -> NaN distance, whose bit pattern exceeds every
+      // threshold (<= 0x7f800000), so tail records need no bounds check in the scan
+      const float qnan = __uint_as_float(0x7fc00000u);
+      float4 v = make_float4(qnan, qnan, qnan, 0.f);
       if (t < T) {
         int r = rh;
         while (s_rowoff[r + 1] <= t) ++r;  // t < T = rowoff[nrows] bounds the walk
@@ -785,13 +788,12 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
                 d = d + dz * dz;
               }
             }
-            const bool live = tb + u < cnt;  // tail of the last tile
             if (kUseQueue) {
-              if (live && __float_as_uint(d) <= thr) {
+              if (__float_as_uint(d) <= thr) {
                 s_queue[qn * kGridWave + lane] = TopKLex<KC>::make(d, __float_as_int(c.w));
                 ++qn;
               }
-            } else if (live && __float_as_uint(d) <= top.worst_bits()) {
+            } else if (__float_as_uint(d) <= top.worst_bits()) {
               const unsigned long long key = TopKLex<KC>::make(d, __float_as_int(c.w));
               if (key < top.key[KC - 1]) top.insert(key);
             }
