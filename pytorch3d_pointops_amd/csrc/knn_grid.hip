@@ -843,6 +843,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
 constexpr int kWaveKernelBlock = 256;
 constexpr int kWaveKernelWgsPerCloud = 64;
 constexpr int kWaveRegionCap = 16384;
+constexpr int kWaveRows = 96;  // (2r+1)^2 rows for r = 2 (25) and r = 4 (81)
 
 template <int D, int KC, int NORM>
 __global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
@@ -850,10 +851,13 @@ __global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
     const int* __restrict__ cell_start, const float4* __restrict__ sorted, const int* __restrict__ fb_count,
     const int* __restrict__ fb_list, int* __restrict__ fb2_count, int* __restrict__ fb2_list, int cell_cap,
     int P1, int P2, int K, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+  __shared__ int s_rowsrc[kWaveKernelBlock / kWave][kWaveRows];
+  __shared__ int s_rowoff[kWaveKernelBlock / kWave][kWaveRows + 1];
   const int n = blockIdx.y;
   const int cnt = fb_count[n];
   if (cnt == 0) return;
   const int lane = threadIdx.x & (kWave - 1);
+  const int wslot = threadIdx.x / kWave;
   const int wave = blockIdx.x * (kWaveKernelBlock / kWave) + threadIdx.x / kWave;
   constexpr int kWavesPerCloud = kWaveKernelWgsPerCloud * (kWaveKernelBlock / kWave);
   const GridCloud g = clouds[n];
@@ -880,39 +884,92 @@ __global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
       const bool whole = !(hx0 || hx1 || hy0 || hy1 || hz0 || hz1);
       TopKLex<KC> top;
       top.init();
+      auto consider = [&](const float4 c) {
+        float d;
+        if (NORM == 1) {
+          d = __builtin_fabsf(qx - c.x);
+          if (D > 1) d = d + __builtin_fabsf(qy - c.y);
+          if (D > 2) d = d + __builtin_fabsf(qz - c.z);
+        } else {
+          const float dx = qx - c.x;
+          d = dx * dx;
+          if (D > 1) {
+            const float dy = qy - c.y;
+            d = d + dy * dy;
+          }
+          if (D > 2) {
+            const float dz = qz - c.z;
+            d = d + dz * dz;
+          }
+        }
+        if (__float_as_uint(d) <= top.worst_bits()) {
+          const unsigned long long key = TopKLex<KC>::make(d, __float_as_int(c.w));
+          if (key < top.key[KC - 1]) top.insert(key);
+        }
+      };
       int scanned = 0;
       bool giveup = false;
-      for (int z = Z0; z <= Z1 && !giveup; ++z) {
-        for (int y = Y0; y <= Y1; ++y) {
-          const int rowbase = (z * g.G[1] + y) * g.G[0];
-          const int s = cstart[rowbase + X0], e = cstart[rowbase + X1 + 1];
-          for (int j = s + lane; j < e; j += kWave) {
-            const float4 c = sp[j];
-            float d;
-            if (NORM == 1) {
-              d = __builtin_fabsf(qx - c.x);
-              if (D > 1) d = d + __builtin_fabsf(qy - c.y);
-              if (D > 2) d = d + __builtin_fabsf(qz - c.z);
-            } else {
-              const float dx = qx - c.x;
-              d = dx * dx;
-              if (D > 1) {
-                const float dy = qy - c.y;
-                d = d + dy * dy;
-              }
-              if (D > 2) {
-                const float dz = qz - c.z;
-                d = d + dz * dz;
-              }
-            }
-            if (__float_as_uint(d) <= top.worst_bits()) {
-              const unsigned long long key = TopKLex<KC>::make(d, __float_as_int(c.w));
-              if (key < top.key[KC - 1]) top.insert(key);
-            }
+      const int ny = Y1 - Y0 + 1, nrows = ny * (Z1 - Z0 + 1);
+      if (nrows <= kWaveRows) {
+        // Small cubes (r = 2, 4): latency-bound if walked row by row (two dependent scalar loads
+        // per row, then one load per lane).  Instead the lanes fetch all row bounds at once,
+        // a wave scan turns them into a flat record stream, and every lane then owns the
+        // records lane, lane+64, ... with four loads in flight.
+        int* __restrict__ rs = s_rowsrc[wslot];
+        int* __restrict__ ro = s_rowoff[wslot];
+        for (int r0 = 0; r0 < nrows; r0 += kWave) {
+          const int rr = r0 + lane;
+          int len_r = 0, src = 0;
+          if (rr < nrows) {
+            const int z = Z0 + rr / ny, y = Y0 + rr % ny;
+            const int rowbase = (z * g.G[1] + y) * g.G[0];
+            src = cstart[rowbase + X0];
+            len_r = cstart[rowbase + X1 + 1] - src;
           }
-          scanned += e - s;
+          int inc = len_r;  // inclusive wave scan
+#pragma unroll
+          for (int off = 1; off < kWave; off <<= 1) {
+            const int v = __shfl_up(inc, off, kWave);
+            if (lane >= off) inc += v;
+          }
+          if (rr < nrows) {
+            rs[rr] = src;
+            ro[rr + 1] = scanned + inc;
+          }
+          scanned += __shfl(inc, kWave - 1, kWave);
         }
-        if (!whole && scanned > kWaveRegionCap) giveup = true;
+        if (lane == 0) ro[0] = 0;
+        const int T = scanned;
+        if (!whole && T > kWaveRegionCap) {
+          giveup = true;
+        } else {
+          int rrow = 0;
+          for (int t0 = lane; t0 < T; t0 += 4 * kWave) {
+            float4 c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int t = t0 + u * kWave;
+              const float qnan = __uint_as_float(0x7fc00000u);
+              c[u] = make_float4(qnan, qnan, qnan, 0.f);
+              if (t < T) {
+                while (ro[rrow + 1] <= t) ++rrow;
+                c[u] = sp[rs[rrow] + (t - ro[rrow])];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) consider(c[u]);
+          }
+        }
+      } else {
+        for (int z = Z0; z <= Z1 && !giveup; ++z) {
+          for (int y = Y0; y <= Y1; ++y) {
+            const int rowbase = (z * g.G[1] + y) * g.G[0];
+            const int s = cstart[rowbase + X0], e = cstart[rowbase + X1 + 1];
+            for (int j = s + lane; j < e; j += kWave) consider(sp[j]);
+            scanned += e - s;
+          }
+          if (!whole && scanned > kWaveRegionCap) giveup = true;
+        }
       }
       if (giveup) {
         if (lane == 0) {
