@@ -147,14 +147,14 @@ __global__ __launch_bounds__(kFpsBlock) void fps_kernel(
 // v2: register-resident clusters.  A cloud is split over G workgroups (G = ceil(P /
 // (PPT*1024)), up to one workgroup per CU); every lane keeps its PPT points AND their
 // running min-distances in VGPRs, so an iteration touches no memory except the
-// exchange: each workgroup reduces its local argmax, publishes it with ONE 64-bit
-// agent-scope atomicMax on the (cloud, iteration) slot -- key = distance bits << 32 |
-// ~index, so the maximum is the largest distance and, on ties, the LOWEST index, i.e.
-// std::max_element's first maximum -- then bumps the slot's arrival counter (release)
-// and polls it (relaxed agent-scope loads + s_sleep) until all G members arrived.
-// Slots are per iteration, zeroed by a memset node before the launch; only agent-scope
-// atomics ever touch them (cdna guide G16 "8-B agent atomics both sides"), the points
-// themselves are read-only input.  All workgroups of the grid are resident by
+// exchange: each workgroup reduces its local argmax and publishes it with ONE relaxed
+// agent-scope 8-byte store into its own slot of the (cloud, iteration) row -- key =
+// distance bits << 32 | ~index, never 0; the key IS the message, so there is no flag, no
+// counter and no fence (cdna guide G16, R2 "the data is the flag") -- then wave 0 polls the
+// G slots of the row (relaxed agent-scope loads + s_sleep) until all are non-zero and
+// takes their maximum: the largest distance and, on ties, the LOWEST index, i.e.
+// std::max_element's first maximum.  Rows are per iteration, zeroed by a memset node before
+// the launch; only agent-scope atomics ever touch them, the points are read-only input.  All workgroups of the grid are resident by
 // construction (grid <= number of CUs, one 1024-lane workgroup per CU), and every spin
 // is bounded.
 // ---------------------------------------------------------------------------
@@ -164,7 +164,7 @@ template <int DT, int PPT>
 __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
     const float* __restrict__ points, const int64_t* __restrict__ lengths,
     const int64_t* __restrict__ Ks, const int64_t* __restrict__ start_idxs, int N, int P, int max_K,
-    int G, int n_clusters, unsigned long long* __restrict__ slots, unsigned* __restrict__ arrive,
+    int G, int n_clusters, unsigned long long* __restrict__ slots,
     unsigned* __restrict__ timeout_flag, int64_t* __restrict__ idxs) {
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -204,8 +204,7 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
     int last = (int)start_idxs[n];
     if (last < 0 || last >= len) last = 0;
     if (member == 0 && tid == 0) out[0] = last;
-    unsigned long long* __restrict__ cslots = slots + (int64_t)n * max_K;
-    unsigned* __restrict__ carrive = arrive + (int64_t)n * max_K;
+    unsigned long long* __restrict__ cslots = slots + (int64_t)n * max_K * G;
 
     for (int k = 1; k < kn; ++k) {
       float c[DT];
@@ -253,26 +252,47 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
           const int oi = __shfl_xor(ix, off, kWave);
           argmax_combine(v, ix, ov, oi);
         }
-        if (lane == 0) {
-          int win = ix;
-          if (G > 1) {
+        int win = ix;  // valid in lane 0
+        if (G > 1) {
+          // Exchange, whole wave 0: lane 0 publishes this member's key with ONE relaxed agent-scope
+          // store into its own slot of the (cloud, iteration) row -- the 8-byte key IS the message
+          // (distance bits << 32 | ~index, never 0), so no flag and no fence are needed; then the
+          // lanes poll the G slots of the row (one 128-byte line for G = 16) until all are non-zero
+          // and take the maximum: largest distance, lowest index on ties.
+          unsigned long long* __restrict__ rowk = cslots + (int64_t)k * G;
+          if (lane == 0) {
             const unsigned long long key =
                 (v >= 0.0f) ? (((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xffffffffu - (unsigned)ix))
-                            : 0ull;  // this member holds no valid point
-            __hip_atomic_fetch_max(cslots + k, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(carrive + k, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                            : 1ull;  // this member holds no valid point (below every real key)
+            __hip_atomic_store(rowk + member, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          unsigned long long best = 0ull;
+          for (int base = 0; base < G; base += kWave) {
+            const int m = base + lane;
+            unsigned long long mine = 1ull;
             unsigned spins = 0;
-            while (__hip_atomic_load(carrive + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G) {
-              __builtin_amdgcn_s_sleep(2);
+            for (;;) {
+              mine = m < G ? __hip_atomic_load(rowk + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1ull;
+              if (__all(mine != 0ull)) break;
+              __builtin_amdgcn_s_sleep(1);
               if (++spins > kFpsSpinLimit) {  // exit condition every wave reaches
-                __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
               }
             }
-            const unsigned long long w = __hip_atomic_load(cslots + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            win = (int)(0xffffffffu - (unsigned)(w & 0xffffffffull));
-            if (win < 0 || win >= len) win = 0;  // only reachable after a timeout
+            best = mine > best ? mine : best;
           }
+#pragma unroll
+          for (int off = kWave / 2; off > 0; off >>= 1) {
+            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), off, kWave);
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best, off, kWave);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            best = o > best ? o : best;
+          }
+          win = (int)(0xffffffffu - (unsigned)(best & 0xffffffffull));
+          if (win < 0 || win >= len) win = 0;  // only reachable after a timeout
+        }
+        if (lane == 0) {
           s_last = win;
           if (member == 0) out[k] = win;
         }
@@ -300,11 +320,22 @@ static int fps_num_cus() {
   return cus;
 }
 
+// cluster geometry of the register-resident kernel: points per lane and workgroups per cloud
+static void fps_plan(int64_t P, int* ppt, int* G) {
+  const int cus = fps_num_cus();
+  int p = P <= 8 * (int64_t)kFpsBlock * cus ? 8 : 16;
+  if (P <= 4 * (int64_t)kFpsBlock) p = 4;
+  *ppt = p;
+  *G = (int)ceil_div(P > 0 ? P : 1, (int64_t)p * kFpsBlock);
+}
+
 extern "C" size_t pointops_fps_workspace_bytes(int64_t N, int64_t P, int64_t max_K) {
-  // v1 running min-distance array (N*P floats) + v2 exchange slots: (u64 slot + u32 arrival) per
-  // (cloud, iteration) + one timeout word
+  // v1 running min-distance array (N*P floats) + v2 exchange rows: one u64 slot per
+  // (cloud, iteration, cluster member) + one timeout word
+  int ppt, G;
+  fps_plan(P, &ppt, &G);
   const size_t md = sizeof(float) * (size_t)(N * P);
-  const size_t ex = (sizeof(unsigned long long) + sizeof(unsigned)) * (size_t)(N * max_K) + 64;
+  const size_t ex = sizeof(unsigned long long) * (size_t)(N * max_K) * (size_t)(G > 1 ? G : 1) + 64;
   return ((md + 255) & ~(size_t)255) + ex;
 }
 
@@ -323,30 +354,27 @@ extern "C" int pointops_sample_farthest_points(const float* points, const int64_
   hipStream_t stream = (hipStream_t)stream_;
   float* min_dist_ws = (float*)workspace;
   char* ex = (char*)workspace + ((sizeof(float) * (size_t)(N * P) + 255) & ~(size_t)255);
+  int ppt, G;
+  fps_plan(P, &ppt, &G);
+  const size_t slot_bytes = sizeof(unsigned long long) * (size_t)(N * max_K) * (size_t)(G > 1 ? G : 1);
   unsigned long long* slots = (unsigned long long*)ex;
-  unsigned* arrive = (unsigned*)(slots + (size_t)(N * max_K));
-  unsigned* timeout_flag = arrive + (size_t)(N * max_K);
+  unsigned* timeout_flag = (unsigned*)(ex + slot_bytes);
 
   // v2 (register-resident clusters) for D in {2,3}: up to PPT*1024 points per workgroup
   const int cus = fps_num_cus();
   if ((D == 3 || D == 2) && P >= 1) {
-    int ppt = P <= 8 * (int64_t)kFpsBlock * cus ? 8 : 16;
-    if (P <= 4 * (int64_t)kFpsBlock) ppt = 4;
-    const int64_t cap = (int64_t)ppt * kFpsBlock;
-    const int G = (int)ceil_div(P, cap);
     if (G <= cus) {
       int n_clusters = cus / G;
       if (n_clusters > N) n_clusters = (int)N;
       if (n_clusters < 1) n_clusters = 1;
       if (G == 1) n_clusters = (int)N;  // no exchange: one independent workgroup per cloud
       if (G > 1) {
-        const size_t zb = (sizeof(unsigned long long) + sizeof(unsigned)) * (size_t)(N * max_K) + 64;
-        if (hipMemsetAsync(ex, 0, zb, stream) != hipSuccess) return check_launch("fps(memset)");
+        if (hipMemsetAsync(ex, 0, slot_bytes + 64, stream) != hipSuccess) return check_launch("fps(memset)");
       }
       const dim3 grid((unsigned)(n_clusters * G)), block(kFpsBlock);
 #define PO_LAUNCH_C(DT, PPT)                                                                         \
   hipLaunchKernelGGL((fps_cluster_kernel<DT, PPT>), grid, block, 0, stream, points, lengths, K, start_idxs, \
-                     (int)N, (int)P, (int)max_K, G, n_clusters, slots, arrive, timeout_flag, idxs)
+                     (int)N, (int)P, (int)max_K, G, n_clusters, slots, timeout_flag, idxs)
       if (D == 3) {
         if (ppt == 4) PO_LAUNCH_C(3, 4);
         else if (ppt == 8) PO_LAUNCH_C(3, 8);
