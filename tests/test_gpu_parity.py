@@ -499,3 +499,80 @@ def test_cfg3_fps_and_ball_query_full_cloud(dev):
     bi, bd = _C.ball_query(pts[:, : b["Q"]].contiguous(), pts, one(b["Q"]), one(b["P"]), b["K"], b["radius"])
     assert hashlib.sha256(bi.cpu().numpy().astype(np.int32).tobytes()).hexdigest() == b["idx_sha256"]
     assert hashlib.sha256(bd.cpu().numpy().tobytes()).hexdigest() == b["dists_sha256"]
+
+
+def test_cfg3_ball_query_full_batch_properties(dev):
+    """BASELINE.json configs[2] ball-query half at full size (B=16, N=131072, r=0.2, K=32):
+    size-independent properties -- indices strictly ascending per row, every listed distance is the
+    unfused fp32 distance of that pair and < r*r, -1 padding only after the hits, and on sampled
+    queries the row is exactly the first K in-radius points of a brute-force torch scan."""
+    from pytorch3d_pointops_amd import _C
+
+    B, P, K, r = 16, 131072, 32, 0.2
+    pts = np.empty((B, P, 3), np.float32)
+    for b in range(B):
+        pts[b] = cases.cloud(7003 + 10 * b, (P, 3))
+    x = G(pts, dev)
+    L = torch.full((B,), P, dtype=torch.int64, device=dev)
+    idx, d = _C.ball_query(x, x, L, L, K, r)
+    valid = idx >= 0
+    r2 = np.float32(r) * np.float32(r)
+    assert bool((d[valid] < float(r2)).all()) and bool((d[~valid] == 0).all())
+    # hits first, then padding; indices ascending
+    assert bool((valid[..., 1:] <= valid[..., :-1]).all())
+    both = valid[..., 1:] & valid[..., :-1]
+    assert bool((idx[..., 1:][both] > idx[..., :-1][both]).all())
+    # distances recomputed from the indices (unfused fp32) are bit-equal
+    safe = idx.clamp(min=0)
+    nb = torch.gather(x, 1, safe.reshape(B, P * K, 1).expand(-1, -1, 3)).reshape(B, P, K, 3)
+    diff = x[:, :, None, :] - nb
+    sq = diff * diff
+    re = (sq[..., 0] + sq[..., 1]) + sq[..., 2]
+    assert torch.equal(re[valid], d[valid])
+    # cloud 0, first 2048 queries == pinned reference digest (tests/golden/big_meta.json)
+    meta = json.load(open(os.path.join(GOLDEN, "big_meta.json")))["cfg3_bq"]
+    i0 = idx[0, : meta["Q"]].cpu().numpy().astype(np.int32)
+    assert hashlib.sha256(i0.tobytes()).hexdigest() == meta["idx_sha256"]
+    # sampled rows against a brute-force scan
+    qs = torch.arange(5, P, 9973, device=dev)
+    for b in (3, B - 1):
+        dq = x[b, qs][:, None, :] - x[b][None, :, :]
+        dq = dq * dq
+        full = (dq[..., 0] + dq[..., 1]) + dq[..., 2]
+        inside = full < float(r2)
+        rank = torch.cumsum(inside.to(torch.int32), 1)
+        for k in range(0, K, 7):
+            want = torch.where((rank == k + 1) & inside, torch.arange(P, device=dev)[None], P).min(1).values
+            want = torch.where(want == P, torch.full_like(want, -1), want)
+            assert torch.equal(want, idx[b, qs, k])
+
+
+def test_cfg4_chamfer_fused_vs_composed(dev, monkeypatch):
+    """BASELINE.json configs[3] shape (B=8, ragged 20k..200k, normals, fwd+bwd): the fused chamfer
+    direction (one forward + one backward kernel) against the composed path built from knn_points /
+    knn_gather / torch ops that the small-size reference goldens pin -- values and all four gradients."""
+    import pytorch3d_pointops_amd.functions.chamfer as ch
+    from pytorch3d_pointops_amd import synth
+
+    Bq = 8
+    l1 = synth.randint(41, 20000, 200000, (Bq,))
+    l2 = synth.randint(42, 20000, 200000, (Bq,))
+    P1, P2 = int(l1.max()), int(l2.max())
+    base = dict(x=synth.uniform_f32(43, (Bq, P1, 3)), y=synth.uniform_f32(44, (Bq, P2, 3)),
+                xn=synth.unit_normals(45, (Bq, P1, 3)), yn=synth.unit_normals(46, (Bq, P2, 3)))
+    w = G(np.linspace(0.5, 1.5, Bq).astype(np.float32), dev)
+
+    def run():
+        t = {k: G(v, dev).requires_grad_(True) for k, v in base.items()}
+        loss, lf = ch.chamfer_distance(t["x"], t["y"], x_lengths=G(l1, dev), y_lengths=G(l2, dev),
+                                       x_features={"normals": t["xn"]}, y_features={"normals": t["yn"]},
+                                       feature_names=["normals"], weights=w, batch_reduction=None)
+        (loss.sum() + lf["normals"].sum()).backward()
+        return loss.detach(), lf["normals"].detach(), {k: v.grad for k, v in t.items()}
+
+    a = run()
+    monkeypatch.setattr(ch, "_fused_direction_ok", lambda *args, **kw: False)
+    b = run()
+    assert close(a[0].cpu().numpy(), b[0].cpu().numpy()) and close(a[1].cpu().numpy(), b[1].cpu().numpy())
+    for k in base:
+        assert close(a[2][k].cpu().numpy(), b[2][k].cpu().numpy(), tol=2e-5), k
