@@ -42,49 +42,62 @@ __global__ __launch_bounds__(kBqBlock) void ball_query_kernel(
     float a[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) a[d] = active ? p1[row * DT + d] : 0.0f;
+    auto dist_to = [&](const float* __restrict__ b) {
+      float acc;
+      {
+        const float diff = a[0] - b[0];
+        acc = diff * diff;
+      }
+#pragma unroll
+      for (int d = 1; d < DT; ++d) {
+        const float diff = a[d] - b[d];
+        acc = acc + diff * diff;
+      }
+      return acc;
+    };
+    // Hits are rare per lane (a few %) but SOME lane of the wave hits on ~90 % of the candidates, so
+    // a per-candidate `if (hit) store` runs its ~15-instruction store block with one or two active
+    // lanes almost every iteration (66 cycles per wave-point measured vs ~26 of arithmetic).  Instead
+    // a group of 32 candidates only accumulates a 32-bit hit mask per lane (branch-free), and one
+    // expansion loop per group then writes the hits in bit (= index) order with every lane that still
+    // has a bit active; its distance is recomputed from the same operands (bit-identical).
+    const int room = active ? K : 0;
     int j = 0;
-    // wave-uniform loop: exit when every lane of the wave is full or inactive
-    while (j < len2 && __any(active && count < K)) {
-      if (j + kBqTile <= len2) {
+    while (j < len2 && __any(count < room)) {
+      unsigned mask = 0u;
+      const int jg = j;
+      const int g_end = (j + 32 < len2) ? j + 32 : len2;
+      for (; j + kBqTile <= g_end; j += kBqTile) {
         float t[kBqTile * DT];
 #pragma unroll
-        for (int u = 0; u < kBqTile * DT; ++u) t[u] = q[(int64_t)j * DT + u];
+        for (int u = 0; u < kBqTile * DT; ++u) t[u] = q[(int64_t)j * DT + u];  // wave-uniform -> s_load
 #pragma unroll
         for (int jj = 0; jj < kBqTile; ++jj) {
-          float acc;
-          {
-            const float diff = a[0] - t[jj * DT];
-            acc = diff * diff;
-          }
+          const float acc = dist_to(t + jj * DT);
+          mask |= (acc < radius2 ? 1u : 0u) << (unsigned)(j - jg + jj);
+        }
+      }
+      for (; j < g_end; ++j) {
+        float t[DT];
 #pragma unroll
-          for (int d = 1; d < DT; ++d) {
-            const float diff = a[d] - t[jj * DT + d];
-            acc = acc + diff * diff;
-          }
-          if (active && count < K && acc < radius2) {
-            orow_i[count] = j + jj;
-            orow_d[count] = acc;
-            ++count;
-          }
-        }
-        j += kBqTile;
-      } else {
-        float acc;
-        {
-          const float diff = a[0] - q[(int64_t)j * DT];
-          acc = diff * diff;
-        }
+        for (int u = 0; u < DT; ++u) t[u] = q[(int64_t)j * DT + u];
+        const float acc = dist_to(t);
+        mask |= (acc < radius2 ? 1u : 0u) << (unsigned)(j - jg);
+      }
+      if (count >= room) mask = 0u;
+      while (__any(mask != 0u)) {
+        if (mask != 0u) {
+          const int b = __builtin_ctz(mask);
+          mask &= mask - 1u;
+          const int jh = jg + b;
+          float pb[DT];
 #pragma unroll
-        for (int d = 1; d < DT; ++d) {
-          const float diff = a[d] - q[(int64_t)j * DT + d];
-          acc = acc + diff * diff;
-        }
-        if (active && count < K && acc < radius2) {
-          orow_i[count] = j;
-          orow_d[count] = acc;
+          for (int d = 0; d < DT; ++d) pb[d] = q[(int64_t)jh * DT + d];  // per-lane gather (L2-resident)
+          orow_i[count] = jh;
+          orow_d[count] = dist_to(pb);
           ++count;
+          if (count >= room) mask = 0u;
         }
-        ++j;
       }
     }
   } else {
