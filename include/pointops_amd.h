@@ -184,6 +184,15 @@ int pointops_chamfer_backward(const float* x, const float* y, const int64_t* idx
                               int abs_cosine, int mean, float* grad_x, float* grad_y,
                               float* const* grad_x_feats, float* const* grad_y_feats, void* stream);
 
+/*
+ * Inverse-CDF sampling -- replaces `_C.sample_pdf` (reference: csrc/sample_pdf/sample_pdf.h:58-78,
+ * CPU semantics sample_pdf_cpu.cpp:19-99, the USE_BINARY_SEARCH build).
+ *   bins (batch, n_bins+1), weights (batch, n_bins), outputs (batch, n_samples) holding the quantiles
+ *   u in [0,1] on entry and the samples on return (in place, like the reference).
+ */
+int pointops_sample_pdf(const float* bins, const float* weights, float* outputs, int64_t batch,
+                        int64_t n_bins, int64_t n_samples, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

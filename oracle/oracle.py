@@ -74,6 +74,8 @@ class Oracle:
                                         ctypes.c_float, _i64p, _f32p]
         L.oracle_sample_farthest_points.argtypes = [_f32p, _i64p, _i64p, _i64p, _i64, _i64, _i64,
                                                     _i64, _i64p]
+        L.oracle_sample_pdf.argtypes = [_f32p, _f32p, _f32p, _i64, _i64, _i64, ctypes.c_float]
+        L.oracle_sample_pdf.restype = None
         L.oracle_packed_to_padded.argtypes = [_f32p, _i64p, _i64, _i64, _i64, _i64, _f32p]
         L.oracle_padded_to_packed.argtypes = [_f32p, _i64p, _i64, _i64, _i64, _i64, _f32p]
         for f in (L.oracle_knn_points_idx, L.oracle_knn_points_backward, L.oracle_ball_query,
@@ -126,6 +128,14 @@ class Oracle:
         out = np.empty((N, max_K), np.int64)
         self.lib.oracle_sample_farthest_points(_pf(points), _pi(lengths), _pi(K), _pi(start_idxs),
                                                N, P, D, max_K, _pi(out))
+        return out
+
+    # -- sample_pdf: returns the samples for quantiles u (the reference works in place) --
+    def sample_pdf(self, bins, weights, u, eps):
+        bins, weights = _f32(bins), _f32(weights)
+        out = np.array(u, dtype=np.float32, copy=True, order="C")
+        B, nb1 = bins.shape
+        self.lib.oracle_sample_pdf(_pf(bins), _pf(weights), _pf(out), B, nb1 - 1, out.shape[1], float(eps))
         return out
 
     # -- packed <-> padded ---------------------------------------------------
@@ -184,6 +194,11 @@ class RefOracle:
         return self.m.sample_farthest_points(self._t(points, np.float32), self._t(lengths, np.int64),
                                              self._t(K, np.int64),
                                              self._t(start_idxs, np.int64)).numpy()
+
+    def sample_pdf(self, bins, weights, u, eps):
+        out = self._t(np.array(u, dtype=np.float32, copy=True), np.float32)
+        self.m.sample_pdf(self._t(bins, np.float32), self._t(weights, np.float32), out, float(eps))
+        return out.numpy()
 
     def packed_to_padded(self, inputs_packed, first_idxs, max_size):
         return self.m.packed_to_padded(self._t(inputs_packed, np.float32),

@@ -289,3 +289,48 @@ void oracle_padded_to_packed(const float* padded, const int64_t* first_idxs,
         packed[(start + i) * D + j] = padded[(b * max_size + i) * D + j];
   }
 }
+
+/*
+ * Inverse-CDF sampling.  Follows SamplePdfCpu_worker, csrc/sample_pdf/sample_pdf_cpu.cpp:23-99,
+ * in the build the reference ships (`#define USE_BINARY_SEARCH`, :19): inclusive fp32 partial
+ * sums of the bin weights in bin order (:52-58), total += eps (:59); per sample
+ * uniform = total * u (:68); i_bin = std::lower_bound over the first n_bins-1 partial sums
+ * (first partial sum that is not < uniform, else n_bins-1) (:70-72); uniform -= partial_sums[i_bin-1]
+ * when i_bin > 0 (:73-75); linear interpolation inside the bin with the `uniform > w` and
+ * `w > eps` guards (:87-95).  In place on `outputs`.
+ */
+void oracle_sample_pdf(const float* bins, const float* weights, float* outputs, int64_t batch,
+                       int64_t n_bins, int64_t n_samples, float eps) {
+  float* partial = (float*)malloc(sizeof(float) * (size_t)(n_bins > 0 ? n_bins : 1));
+  for (int64_t b = 0; b < batch; ++b) {
+    const float* bin = bins + b * (n_bins + 1);
+    const float* w = weights + b * n_bins;
+    float total = 0;
+    for (int64_t i = 0; i < n_bins; ++i) {
+      total += w[i];
+      partial[i] = total;
+    }
+    total += eps;
+    for (int64_t s = 0; s < n_samples; ++s) {
+      float* o = outputs + b * n_samples + s;
+      float uniform = total * *o;
+      int64_t lo = 0, hi = n_bins - 1; /* lower_bound on [0, n_bins-1) */
+      while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (partial[mid] < uniform) lo = mid + 1;
+        else hi = mid;
+      }
+      const int64_t i = lo;
+      if (i > 0) uniform -= partial[i - 1];
+      const float bin_start = bin[i], bin_end = bin[i + 1], bin_weight = w[i];
+      float v = bin_start;
+      if (uniform > bin_weight) {
+        v = bin_end;
+      } else if (bin_weight > eps) {
+        v += (uniform / bin_weight) * (bin_end - bin_start);
+      }
+      *o = v;
+    }
+  }
+  free(partial);
+}

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "pointops_gather_neighbors_backward": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp,
                                                   _vp]),
     "pointops_chamfer_reduce": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),
+    "pointops_sample_pdf": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp]),
     "pointops_chamfer_workspace_bytes": (_sz, [_i64, _i64]),
     "pointops_chamfer_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _int,
                                         _int, _vp, _vp, _sz, _vp]),
@@ -102,7 +103,13 @@ def _contig(t, name):
         raise RuntimeError(f"{name} must be contiguous")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (as an int)."""
+    if _raw_stream is not None:  # one C call instead of building a torch.cuda.Stream object
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -274,6 +281,25 @@ def padded_to_packed(inputs_padded, first_idxs, num_inputs: int):
             "padded_to_packed",
         )
     return out
+
+
+# reference: csrc/sample_pdf/sample_pdf.h:58-78 -- in place on `outputs`, returns None
+def sample_pdf(bins, weights, outputs, eps: float):
+    dev = _require_gpu(bins, weights, outputs)
+    if bins.dtype != torch.float32 or weights.dtype != torch.float32 or outputs.dtype != torch.float32:
+        raise RuntimeError("expected scalar type Float")
+    if not outputs.is_contiguous():
+        raise RuntimeError("outputs must be contiguous")  # CHECK_CONTIGUOUS (sample_pdf.h:74)
+    bins, weights = bins.contiguous(), weights.contiguous()
+    batch, n_bins = weights.shape
+    if bins.shape != (batch, n_bins + 1) or outputs.shape[0] != batch:
+        raise RuntimeError("sample_pdf: inconsistent shapes")
+    with torch.cuda.device(dev):
+        _check(
+            _lib.pointops_sample_pdf(bins.data_ptr(), weights.data_ptr(), outputs.data_ptr(), batch, n_bins,
+                                     outputs.shape[1], float(eps), _stream()),
+            "sample_pdf",
+        )
 
 
 # --- device halves of knn_gather / masked_gather (functions/knn.py:200-250) -------

@@ -9,7 +9,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
-from .knn import _KNN
+from .knn import _KNN, _full_lengths
 from .utils import masked_gather
 
 
@@ -63,9 +63,9 @@ def ball_query(
     N = p1.shape[0]
 
     if lengths1 is None:
-        lengths1 = torch.full((N,), P1, dtype=torch.int64, device=p1.device)
+        lengths1 = _full_lengths(N, P1, p1.device)
     if lengths2 is None:
-        lengths2 = torch.full((N,), P2, dtype=torch.int64, device=p1.device)
+        lengths2 = _full_lengths(N, P2, p1.device)
 
     dists, idx = _ball_query.apply(p1, p2, lengths1, lengths2, K, radius)
     points_nn = masked_gather(p2, idx) if return_nn else None

@@ -14,6 +14,21 @@ from .. import _C
 
 _KNN = namedtuple("KNN", "dists idx knn")
 
+_full_lengths_cache = {}
+
+
+def _full_lengths(n: int, p: int, device) -> torch.Tensor:
+    """(n,) int64 tensor filled with p: the default `lengths` (reference: functions/knn.py:184-187).
+    Read-only for the kernels, so one cached tensor per (n, p, device) saves a fill launch per call."""
+    key = (n, p, device)
+    t = _full_lengths_cache.get(key)
+    if t is None:
+        if len(_full_lengths_cache) > 64:
+            _full_lengths_cache.clear()
+        t = torch.full((n,), p, dtype=torch.int64, device=device)
+        _full_lengths_cache[key] = t
+    return t
+
 
 class _knn_points(Function):
     """autograd wrapper around the HIP KNN kernels (reference: functions/knn.py:21-111).
@@ -81,9 +96,9 @@ def knn_points(
     P2 = p2.shape[1]
 
     if lengths1 is None:
-        lengths1 = torch.full((p1.shape[0],), P1, dtype=torch.int64, device=p1.device)
+        lengths1 = _full_lengths(p1.shape[0], P1, p1.device)
     if lengths2 is None:
-        lengths2 = torch.full((p1.shape[0],), P2, dtype=torch.int64, device=p1.device)
+        lengths2 = _full_lengths(p1.shape[0], P2, p1.device)
 
     p1_dists, p1_idx = _knn_points.apply(p1, p2, lengths1, lengths2, K, version, norm, return_sorted)
 

@@ -167,3 +167,21 @@ def chamfer_variants():
 
 def variant_key(v):
     return "pr={point_reduction}|br={batch_reduction}|sd={single_directional}|w={use_weights}|f={features}|abs={abs_cosine}|n={norm}".format(**v)
+
+
+# ---------------------------------------------------------------- sample_pdf
+def sample_pdf_cases():
+    """bins sorted in [0,1), non-negative weights (some empty bins), quantiles u incl. 0 and 1.
+    Batch sizes avoid 5: the reference's CPU thread partition (sample_pdf_cpu.cpp:120-141) hands
+    thread 3 the rows [4,6) of a 5-row batch and writes out of bounds."""
+    c = {}
+    for name, (batch, nb, ns, seed) in {"b8_64x128": (8, 64, 128, 701), "b12_7x33": (12, 7, 33, 702),
+                                        "b1_1x5": (1, 1, 5, 703), "b4_128x64": (4, 128, 64, 704)}.items():
+        bins = np.sort(synth.uniform_f32(seed, (batch, nb + 1)), axis=1).astype(np.float32)
+        w = synth.uniform_f32(seed + 10, (batch, nb))
+        w[0, : nb // 3] = 0.0
+        u = synth.uniform_f32(seed + 20, (batch, ns))
+        u[0, 0] = 0.0
+        u[0, -1] = 1.0
+        c[name] = dict(bins=bins, weights=w, u=u, eps=1e-5)
+    return c

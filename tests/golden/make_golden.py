@@ -219,6 +219,21 @@ def gen_chamfer():
     save("chamfer", **out)
 
 
+def gen_sample_pdf():
+    from pytorch3d_pointops.functions.sample_pdf import sample_pdf as ref_sample_pdf
+
+    out = {}
+    for name, c in cases.sample_pdf_cases().items():
+        o = T(c["u"].copy())
+        ref_C.sample_pdf(T(c["bins"]), T(c["weights"]), o, c["eps"])
+        out[name + "/samples"] = o.numpy()
+    # wrapper, deterministic quantiles, batch shape (2, 4)
+    c = cases.sample_pdf_cases()["b8_64x128"]
+    det = ref_sample_pdf(T(c["bins"]).reshape(2, 4, -1), T(c["weights"]).reshape(2, 4, -1), 40, det=True)
+    out["wrapper_det/samples"] = det.numpy()
+    save("sample_pdf", **out)
+
+
 def gen_big():
     """cfg2-size single clouds: digests + sampled rows (the full idx would be 8 MB per cloud)."""
     meta = {}
@@ -265,5 +280,6 @@ if __name__ == "__main__":
     gen_packed()
     gen_gather()
     gen_chamfer()
+    gen_sample_pdf()
     if "--big" in sys.argv:
         gen_big()

@@ -576,3 +576,40 @@ def test_cfg4_chamfer_fused_vs_composed(dev, monkeypatch):
     assert close(a[0].cpu().numpy(), b[0].cpu().numpy()) and close(a[1].cpu().numpy(), b[1].cpu().numpy())
     for k in base:
         assert close(a[2][k].cpu().numpy(), b[2][k].cpu().numpy(), tol=2e-5), k
+
+
+# ------------------------------------------------------------------ sample_pdf
+@pytest.mark.parametrize("name", sorted(cases.sample_pdf_cases()))
+def test_sample_pdf(dev, oracle, name):
+    from pytorch3d_pointops_amd import _C
+
+    g = load_golden("sample_pdf")
+    c = cases.sample_pdf_cases()[name]
+    out = G(c["u"].copy(), dev)
+    _C.sample_pdf(G(c["bins"], dev), G(c["weights"], dev), out, c["eps"])
+    got = out.cpu().numpy()
+    assert np.array_equal(bits(got), bits(g[name + "/samples"]))
+    assert np.array_equal(bits(got), bits(oracle.sample_pdf(c["bins"], c["weights"], c["u"], c["eps"])))
+
+
+def test_sample_pdf_wrapper(dev):
+    from pytorch3d_pointops_amd.functions.sample_pdf import sample_pdf, sample_pdf_python
+
+    g = load_golden("sample_pdf")
+    c = cases.sample_pdf_cases()["b8_64x128"]
+    bins = G(c["bins"], dev).reshape(2, 4, -1)
+    w = G(c["weights"], dev).reshape(2, 4, -1)
+    det = sample_pdf(bins, w, 40, det=True)
+    assert tuple(det.shape) == (2, 4, 40)
+    assert np.array_equal(bits(det.cpu().numpy()), bits(g["wrapper_det/samples"]))
+    # random quantiles: samples stay inside the bin range and roughly follow the python variant
+    torch.manual_seed(0)
+    rnd = sample_pdf(bins, w, 64)
+    assert bool((rnd >= bins[..., :1]).all()) and bool((rnd <= bins[..., -1:]).all())
+    assert close(sample_pdf_python(bins, w, 40, det=True).cpu().numpy(), det.cpu().numpy(), tol=1e-3)
+    with pytest.raises(ValueError, match="Negative weights"):
+        sample_pdf(bins, w - 1.0, 4)
+    with pytest.raises(ValueError, match="Inconsistent shapes"):
+        sample_pdf(bins[..., :-1], w, 4)
+    with pytest.raises(NotImplementedError):
+        sample_pdf(bins, w.clone().requires_grad_(True), 4)

@@ -114,3 +114,11 @@ def test_big_golden_rows_oracle(oracle):
     idx, d = oracle.knn_points_idx(p1[:, rows], p2, np.array([len(rows)]), np.array([P]), 2, K)
     assert np.array_equal(idx[0], g["cfg2_cloud/idx_rows"][: len(rows)].astype(np.int64))
     assert np.array_equal(bits(d[0]), bits(g["cfg2_cloud/dists_rows"][: len(rows)]))
+
+
+@pytest.mark.parametrize("name", sorted(cases.sample_pdf_cases()))
+def test_sample_pdf_oracle(oracle, name):
+    g = load_golden("sample_pdf")
+    c = cases.sample_pdf_cases()[name]
+    got = oracle.sample_pdf(c["bins"], c["weights"], c["u"], c["eps"])
+    assert np.array_equal(bits(got), bits(g[name + "/samples"]))
