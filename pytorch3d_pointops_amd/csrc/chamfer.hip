@@ -247,6 +247,94 @@ __global__ __launch_bounds__(kCfBlock) void chamfer_backward_kernel(
   }
 }
 
+
+// Channel-parallel backward for D <= 4 and C <= 4 (points + normals/colours): FOUR lanes per
+// point, lane c owning coordinate / channel c.  The scatter into grad_y / grad_y_feat is bound by
+// the memory-side fp32 atomic rate, which depends on how many distinct rows one wave instruction
+// touches (64 different rows is ~17x slower than contiguous bytes: MI355X_MICROARCH.md, global
+// float atomics).  With a lane per point the three coordinates of a target row leave in three
+// instructions of 64 rows each; here they leave in ONE instruction covering 16 rows x 12-16
+// contiguous bytes.  The per-point scalars (norms, cosine) are recomputed by the four lanes.
+template <int NORM>
+__global__ __launch_bounds__(kCfBlock) void chamfer_backward4_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const int64_t* __restrict__ idx,
+    const int64_t* __restrict__ x_lengths, const int64_t* __restrict__ y_lengths,
+    const float* __restrict__ weights, const float* __restrict__ grad_out, int N, int64_t P1, int64_t P2, int D,
+    ChamferFeat ft, int abs_cosine, int mean, float* __restrict__ grad_x, float* __restrict__ grad_y) {
+  const int n = blockIdx.y;
+  const int64_t t = (int64_t)blockIdx.x * kCfBlock + threadIdx.x;
+  const int64_t i = t >> 2;
+  const int c = (int)(t & 3);
+  if (i >= P1) return;
+  int64_t len = x_lengths[n];
+  if (len > P1) len = P1;
+  const int64_t row = (int64_t)n * P1 + i;
+  const bool y_valid = y_lengths[n] > 0;
+  if (i >= len) {
+    if (c < D) grad_x[row * D + c] = 0.0f;
+#pragma unroll
+    for (int f = 0; f < kCfMaxFeat; ++f)
+      if (f < ft.F && c < ft.C[f]) ft.gx[f][row * ft.C[f] + c] = 0.0f;
+    return;
+  }
+  float scale = weights != nullptr ? weights[n] : 1.0f;
+  if (mean) scale /= (float)(len < 1 ? 1 : len);
+  const int64_t j = idx[row];
+  const int64_t yrow = (int64_t)n * P2 + j;
+  if (c < D) {
+    const float a = grad_out[n] * scale;
+    float diff = 0.0f;
+    if (y_valid) {
+      const float xv = x[row * D + c], yv = y[yrow * D + c];
+      if (NORM == 1) diff = a * ((xv > yv) ? 1.0f : -1.0f);
+      else diff = 2.0f * a * (xv - yv);
+      if (diff != 0.0f) atomicAdd(grad_y + yrow * D + c, -1.0f * diff);
+    }
+    grad_x[row * D + c] = diff;
+  }
+#pragma unroll
+  for (int f = 0; f < kCfMaxFeat; ++f) {
+    if (f >= ft.F) continue;
+    const int C = ft.C[f];
+    // norms and cosine of the (<= 4-channel) pair, same summation order as cf_cosine
+    float xv[4], yv[4];
+    float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xv[k] = k < C ? ft.x[f][row * C + k] : 0.0f;
+      yv[k] = (k < C && y_valid) ? ft.y[f][yrow * C + k] : 0.0f;
+      sx += xv[k] * xv[k];
+      sy += yv[k] * yv[k];
+    }
+    const float eps = 1e-6f;
+    const float nx = sqrtf(sx), ny = sqrtf(sy);
+    const float ix = 1.0f / fmaxf(nx, eps), iy = 1.0f / fmaxf(ny, eps);
+    float cosv = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xv[k] *= ix;
+      yv[k] *= iy;
+      cosv += xv[k] * yv[k];
+    }
+    if (c < C) {
+      float sgn = -1.0f;
+      if (abs_cosine) sgn = cosv > 0.0f ? -1.0f : (cosv < 0.0f ? 1.0f : 0.0f);
+      const float b = grad_out[(int64_t)(1 + f) * N + n] * scale * sgn;
+      float xc = 0.0f, yc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // static select keeps xv / yv in registers
+        xc = (k == c) ? xv[k] : xc;
+        yc = (k == c) ? yv[k] : yc;
+      }
+      ft.gx[f][row * C + c] = b * ix * (nx > eps ? (yc - cosv * xc) : yc);
+      if (y_valid) {
+        const float gy = b * iy * (ny > eps ? (xc - cosv * yc) : xc);
+        if (gy != 0.0f) atomicAdd(ft.gy[f] + yrow * C + c, gy);
+      }
+    }
+  }
+}
+
 }  // namespace pointops
 
 extern "C" size_t pointops_chamfer_workspace_bytes(int64_t N, int64_t P1) {
@@ -313,6 +401,18 @@ extern "C" int pointops_chamfer_backward(const float* x, const float* y, const i
         hipMemsetAsync(grad_y_feats[f], 0, sizeof(float) * (size_t)(N * P2 * C[f]), stream) != hipSuccess)
       return check_launch("chamfer_backward(memset)");
   if (N == 0 || P1 == 0) return POINTOPS_OK;
+  bool four = D <= 4;
+  for (int f = 0; f < F; ++f) four = four && C[f] <= 4;
+  if (four) {
+    const dim3 grid4((unsigned)ceil_div(P1 * 4, kCfBlock), (unsigned)N), block4(kCfBlock);
+    if (norm == 1)
+      hipLaunchKernelGGL(chamfer_backward4_kernel<1>, grid4, block4, 0, stream, x, y, idx, x_lengths, y_lengths,
+                         weights, grad_out, (int)N, P1, P2, (int)D, ft, abs_cosine, mean, grad_x, grad_y);
+    else
+      hipLaunchKernelGGL(chamfer_backward4_kernel<2>, grid4, block4, 0, stream, x, y, idx, x_lengths, y_lengths,
+                         weights, grad_out, (int)N, P1, P2, (int)D, ft, abs_cosine, mean, grad_x, grad_y);
+    return check_launch("chamfer_backward");
+  }
   const dim3 grid((unsigned)ceil_div(P1, kCfBlock), (unsigned)N), block(kCfBlock);
   if (norm == 1)
     hipLaunchKernelGGL(chamfer_backward_kernel<1>, grid, block, 0, stream, x, y, idx, x_lengths, y_lengths, weights,
