@@ -83,6 +83,50 @@ __global__ __launch_bounds__(kBwdBlock) void knn_backward_kernel(
   }
 }
 
+
+// D <= 4: FOUR lanes per query, lane c owning coordinate c.  grad_p1[n,i,c] is still one lane's
+// register sum in k order (bit-equal to the CPU loop); the grad_p2 atomics of one neighbour row
+// now leave as ONE wave instruction over 16 rows x 12-16 contiguous bytes instead of three
+// instructions over 64 different rows each (the memory-side fp32 atomic rate depends on the rows
+// touched per instruction: MI355X_MICROARCH.md, global float atomics).
+template <int NORM>
+__global__ __launch_bounds__(kBwdBlock) void knn_backward4_kernel(
+    const float* __restrict__ p1, const float* __restrict__ p2,
+    const int64_t* __restrict__ lengths1, const int64_t* __restrict__ lengths2,
+    const int64_t* __restrict__ idxs, const float* __restrict__ grad_dists, int P1, int P2, int D, int K,
+    int tiles_per_cloud, float* __restrict__ grad_p1, float* __restrict__ grad_p2) {
+  const int n = blockIdx.x / tiles_per_cloud;
+  const int tile = blockIdx.x - n * tiles_per_cloud;
+  const int t = tile * kBwdBlock + threadIdx.x;
+  const int i = t >> 2, c = t & 3;
+  if (i >= P1 || c >= D) return;
+  const int len1 = (int)lengths1[n];
+  const int64_t len2 = lengths2[n];
+  const int kmax = (int)(len2 < K ? len2 : K);
+  const int64_t row = (int64_t)n * P1 + i;
+  if (i >= len1) {
+    grad_p1[row * D + c] = 0.0f;
+    return;
+  }
+  const int64_t* __restrict__ irow = idxs + row * K;
+  const float* __restrict__ grow = grad_dists + row * K;
+  const float av = p1[row * D + c];
+  float acc = 0.0f;
+  for (int k = 0; k < kmax; ++k) {
+    const int64_t i2 = irow[k];
+    if (i2 < 0 || i2 >= P2) continue;  // -1 padding (ball query); also guards bad input
+    const float g = grow[k];
+    const int64_t o = ((int64_t)n * P2 + i2) * D + c;
+    const float bv = p2[o];
+    float diff;
+    if (NORM == 1) diff = g * ((av > bv) ? 1.0f : -1.0f);
+    else diff = 2.0f * g * (av - bv);
+    acc = acc + diff;
+    if (diff != 0.0f) atomicAdd(grad_p2 + o, -1.0f * diff);
+  }
+  grad_p1[row * D + c] = acc;
+}
+
 }  // namespace pointops
 
 using namespace pointops;
@@ -102,6 +146,18 @@ extern "C" int pointops_knn_points_backward(const float* p1, const float* p2,
       return check_launch("knn_points_backward(memset)");
   }
   if (N == 0 || P1 == 0) return POINTOPS_OK;
+  if (D <= 4) {
+    const int tiles4 = (int)ceil_div(P1 * 4, kBwdBlock);
+    POINTOPS_REQUIRE(N * tiles4 < (1LL << 31), "knn_points_backward: grid too large");
+    const dim3 grid4((unsigned)(N * tiles4)), block4(kBwdBlock);
+    if (norm == 1)
+      hipLaunchKernelGGL(knn_backward4_kernel<1>, grid4, block4, 0, stream, p1, p2, lengths1, lengths2, idxs,
+                         grad_dists, (int)P1, (int)P2, (int)D, (int)K, tiles4, grad_p1, grad_p2);
+    else
+      hipLaunchKernelGGL(knn_backward4_kernel<2>, grid4, block4, 0, stream, p1, p2, lengths1, lengths2, idxs,
+                         grad_dists, (int)P1, (int)P2, (int)D, (int)K, tiles4, grad_p1, grad_p2);
+    return check_launch("knn_points_backward");
+  }
   const int tiles = (int)ceil_div(P1, kBwdBlock);
   POINTOPS_REQUIRE(N * tiles < (1LL << 31), "knn_points_backward: grid too large");
   const dim3 grid((unsigned)(N * tiles)), block(kBwdBlock);

@@ -40,7 +40,7 @@ def emit(name, ms, mn, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ops", default="bq,fps,chamfer,packed,gather,knn_small")
+    ap.add_argument("--ops", default="bq,fps,chamfer,packed,gather,knn_bwd,knn_small")
     args = ap.parse_args()
     ops = args.ops.split(",")
     dev = torch.device("cuda:0")
@@ -97,6 +97,15 @@ def main():
         ig = torch.from_numpy(synth.randint(62, 0, Pg - 1, (Bg, Pg, Kg))).to(dev)
         ms, mn = timeit(lambda: knn_gather(xg, ig))
         emit("knn_gather B=32 N=65536 K=16 U=3", ms, mn, algo_GBs=(Bg * Pg * Kg * (8 + 12) + Bg * Pg * 12) / ms / 1e6)
+    if "knn_bwd" in ops:
+        Bb, Pb, Kb = 32, 65536, 16
+        a = torch.from_numpy(synth.uniform_f32(81, (Bb, Pb, 3))).to(dev)
+        c = torch.from_numpy(synth.uniform_f32(82, (Bb, Pb, 3))).to(dev)
+        Lb = torch.full((Bb,), Pb, dtype=torch.int64, device=dev)
+        idx, _ = _C.knn_points_idx(a, c, Lb, Lb, 2, Kb, -1)
+        gd = torch.from_numpy(synth.uniform_f32(83, (Bb, Pb, Kb))).to(dev)
+        ms, mn = timeit(lambda: _C.knn_points_backward(a, c, Lb, Lb, idx, 2, gd))
+        emit("knn_points_backward B=32 N=65536 K=16", ms, mn, atomics_per_s=Bb * Pb * Kb * 3 / ms * 1e3)
     if "knn_small" in ops:
         for (b, n, k) in ((2, 1024, 8), (32, 4096, 16), (8, 65536, 1)):
             a = torch.from_numpy(synth.uniform_f32(71, (b, n, 3))).to(dev)
