@@ -10,25 +10,29 @@
 // B=32, N=M=65536, K=16) towards the HBM floor (72 us).
 //
 // Passes (all clouds of the batch in every launch, no host synchronisation):
-//   1 grid_setup     per cloud: bbox of p2, cubic cell size h for ~K/2 points per cell,
-//                    G = cells per dimension, and per-dimension EDGE TABLES
+//   0 grid_bbox      bounding box of every p2 cloud (ordered-uint atomicMin/Max);
+//   1 grid_setup     per cloud: cubic cell size h for ~0.4 K points per cell (>= 1), G = cells
+//                    per dimension, and per-dimension EDGE TABLES
 //                    E_d[c] = min{ x in [lo,hi] : cell_d(x) >= c }, found by bisection over
 //                    the ordered fp32 bit patterns of the (monotone) cell function
 //                    itself -- no error analysis of the binning arithmetic is needed;
-//   2 grid_count     histogram of p2 points per cell and of p1 queries per BLOCK of
-//                    B^3 cells (atomics); zero rows for padded queries;
-//   3 grid_scan      exclusive scans -> cell_start / blk_start;
-//   4 grid_scatter   counting-sort p2 into (x,y,z,idx) float4 records, queries into
+//   2 grid_bin<cnt>  histograms: p2 points per cell, p1 queries per BLOCK of B^3 cells
+//                    (LDS-aggregated, one global atomic per non-empty bin and tile); zero
+//                    rows for padded queries;
+//   3 grid_scan_*    chunked exclusive scans -> cell_start / blk_start;
+//   4 grid_bin<sct>  counting-sort p2 into (x,y,z,idx) float4 records, queries into
 //                    per-block lists;
-//   5 knn_grid       persistent wave64 workgroups walk (cloud, block) items: the <= 64
-//                    queries of a chunk sit one per lane; the block's cells plus a one
-//                    cell halo are streamed row by row through the SCALAR path (the
-//                    records of a row are contiguous in the sorted array and the address
-//                    is wave-uniform) exactly like the all-pairs scan, but over ~500
-//                    candidates instead of the whole cloud.  Afterwards each lane checks
-//                    kth_dist < LB, LB = min over the region's faces of the bound below;
-//                    on failure the query id goes to the fallback list;
-//   6 fallback       knn_reg_kernel over the fallback lists (whole-cloud scan).
+//   5 knn_grid       persistent wave64 workgroups walk (block, 64-query chunk) slots: one
+//                    query per lane; the records of the block's cells plus a one-cell halo
+//                    form a flat stream of contiguous runs that is staged tile by tile in
+//                    LDS and read back with wave-uniform (broadcast) ds_reads; candidates
+//                    that beat a lane's threshold are parked in per-lane LDS queues and merged
+//                    into the sorted register lists by sorting networks.  Afterwards each
+//                    lane checks kth_dist < LB, LB = min over the region's faces of the bound
+//                    below; on failure the query id goes to the fallback list;
+//   6 knn_grid_wave  wave-per-query search of a cell cube that doubles until certified;
+//   7 knn_reg_kernel whole-cloud scan (knn.hip) for the queries pass 6 gave up on and for
+//                    clouds without a usable grid.
 //
 // Lower bound.  Let the visited region be cells [X0..X1]x[Y0..Y1]x[Z0..Z1].  A point in
 // an unvisited cell has, in some dimension d, cell_d < X0 or cell_d > X1.  cell_d is
