@@ -290,13 +290,15 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
 // Chunk k of block b lives in slot  (blk_start[b] >> 6) + b + k : the slot ranges of
 // consecutive blocks never overlap (floor((s+q)/64) - floor(s/64) + 1 >= ceil(q/64)) and a
 // cloud needs at most len1/64 + nblock + 1 slots; empty slots are skipped.
-__global__ void grid_prefix_kernel(GridWs ws, int N) {
+__global__ void grid_prefix_kernel(GridWs ws, int N, int lane_mode) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int acc = 0;
     ws.block_prefix[0] = 0;
     for (int n = 0; n < N; ++n) {
       const GridCloud g = ws.cloud[n];
-      acc += g.use_grid ? (g.len1 / kGridWave + g.nblock + 1) : 0;
+      int items = 0;
+      if (g.use_grid) items = lane_mode ? (g.len1 + kGridWave - 1) / kGridWave : (g.len1 / kGridWave + g.nblock + 1);
+      acc += items;
       ws.block_prefix[n + 1] = acc;
     }
   }
@@ -835,6 +837,186 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// pass 5 (lane-private form): one query per lane, EVERY lane walks only the 3x3x3 cell cube
+// around its own cell (9 contiguous runs of the sorted array), fetched with per-lane 16-byte
+// loads, four in flight.  The queries are sorted by cell (block edge 1), so the 64 lanes of a
+// wave sit in ~10 neighbouring cells and their runs overlap in L1/L2.  Compared with the
+// block-shared broadcast form above this visits ~27 c instead of 64 c candidates per query and
+// fills all 64 lanes of every wave (a block of 2^3 cells holds ~50 queries), at the price of
+// per-lane addressing; the selection core (stale-threshold queues merged by sorting networks)
+// and the certification bound are the same, evaluated on the lane's own cube.
+// ---------------------------------------------------------------------------
+constexpr int kLaneRows = 9;
+
+template <int D, int KC, int NORM>
+__global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
+    const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const int* __restrict__ chunk_prefix,
+    const float* __restrict__ edges, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
+    const int* __restrict__ qlist, int* __restrict__ fb_count, int* __restrict__ fb_list, int cell_cap, int P1,
+    int P2, int K, int N, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+  constexpr bool kUseQueue = KC >= 8 && (KC & (KC - 1)) == 0;
+  constexpr int kQueueCap = KC < 16 ? KC : 16;
+  constexpr int kSub = 4;
+  __shared__ unsigned long long s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
+  __shared__ int2 s_rows[kLaneRows][kGridWave];  // per-lane (first record, end) of its 9 runs
+
+  const int lane = threadIdx.x;
+  const int total = chunk_prefix[N];
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    int lo_n = 0, hi_n = N;
+    while (hi_n - lo_n > 1) {
+      const int mid = (lo_n + hi_n) >> 1;
+      if (chunk_prefix[mid] <= item) lo_n = mid;
+      else hi_n = mid;
+    }
+    const int n = lo_n;
+    const GridCloud g = clouds[n];
+    const int c0 = (item - chunk_prefix[n]) * kGridWave;
+    const bool active = c0 + lane < g.len1;
+    const int qi = active ? qlist[(int64_t)n * P1 + c0 + lane] : 0;
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (active) load_point3<D>(p1 + ((int64_t)n * P1 + qi) * D, qx, qy, qz);
+    int cx, cy, cz;
+    point_cells(g, qx, qy, qz, cx, cy, cz);
+    const int X0 = max(cx - 1, 0), X1 = min(cx + 1, g.G[0] - 1);
+    const int Y0 = max(cy - 1, 0), Y1 = min(cy + 1, g.G[1] - 1);
+    const int Z0 = max(cz - 1, 0), Z1 = min(cz + 1, g.G[2] - 1);
+    const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
+    const float4* __restrict__ sp = sorted + (int64_t)n * P2;
+
+    // the lane's 9 runs, own row first (near-first order tightens the thresholds early)
+#pragma unroll
+    for (int r = 0; r < kLaneRows; ++r) {
+      constexpr int kDz[kLaneRows] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+      constexpr int kDy[kLaneRows] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+      const int z = cz + kDz[r], y = cy + kDy[r];
+      int2 se = make_int2(0, 0);
+      if (active && z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1]) {
+        const int rowbase = (z * g.G[1] + y) * g.G[0];
+        se.x = cstart[rowbase + X0];
+        se.y = cstart[rowbase + X1 + 1];
+      }
+      s_rows[r][lane] = se;
+    }
+    int r = 0;
+    int cur = s_rows[0][lane].x, end = s_rows[0][lane].y;
+    auto next_record = [&]() -> int {  // index of the lane's next record, -1 when exhausted
+      while (cur >= end && r < kLaneRows - 1) {
+        ++r;
+        const int2 se = s_rows[r][lane];
+        cur = se.x;
+        end = se.y;
+      }
+      return cur < end ? cur++ : -1;
+    };
+
+    TopKLex<KC> top;
+    top.init();
+    unsigned thr = 0x7f800000u;
+    int qn = 0;
+    auto flush = [&]() {
+      unsigned long long qk[kQueueCap];
+#pragma unroll
+      for (int t = 0; t < kQueueCap; ++t) {
+        const unsigned long long v = s_queue[t * kGridWave + lane];
+        qk[t] = t < qn ? v : TopKLex<KC>::kEmpty;
+      }
+      bitonic_sort<kQueueCap>(qk);
+#pragma unroll
+      for (int t = 0; t < kQueueCap; ++t) {
+        const unsigned long long a = top.key[KC - 1 - t];
+        top.key[KC - 1 - t] = qk[t] < a ? qk[t] : a;
+      }
+      bitonic_merge<KC>(top.key);
+      qn = 0;
+      thr = top.worst_bits();
+    };
+
+    // software pipeline: the loads of group g+1 are issued before group g is processed
+    auto fetch = [&](float4 (&c)[kSub]) -> bool {
+      int a[kSub];
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) a[u] = next_record();
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) {
+        const float qnan = __uint_as_float(0x7fc00000u);
+        c[u] = make_float4(qnan, qnan, qnan, 0.f);  // exhausted lanes: NaN distance, never passes
+        if (a[u] >= 0) c[u] = sp[a[u]];
+      }
+      return a[0] >= 0;
+    };
+    float4 c[kSub];
+    bool more = fetch(c);
+    while (__any(more)) {
+      float4 nxt[kSub];
+      const bool more_next = fetch(nxt);
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) {
+        float d;
+        if (NORM == 1) {
+          d = __builtin_fabsf(qx - c[u].x);
+          if (D > 1) d = d + __builtin_fabsf(qy - c[u].y);
+          if (D > 2) d = d + __builtin_fabsf(qz - c[u].z);
+        } else {
+          const float dx = qx - c[u].x;
+          d = dx * dx;
+          if (D > 1) {
+            const float dy = qy - c[u].y;
+            d = d + dy * dy;
+          }
+          if (D > 2) {
+            const float dz = qz - c[u].z;
+            d = d + dz * dz;
+          }
+        }
+        if (kUseQueue) {
+          if (__float_as_uint(d) <= thr) {
+            s_queue[qn * kGridWave + lane] = TopKLex<KC>::make(d, __float_as_int(c[u].w));
+            ++qn;
+          }
+        } else if (__float_as_uint(d) <= top.worst_bits()) {
+          const unsigned long long key = TopKLex<KC>::make(d, __float_as_int(c[u].w));
+          if (key < top.key[KC - 1]) top.insert(key);
+        }
+      }
+      if (kUseQueue) {
+        if (__any(qn > kQueueCap - kSub)) flush();
+      }
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) c[u] = nxt[u];
+      more = more_next;
+    }
+    if (kUseQueue) flush();
+
+    // certification against the faces of the lane's own cube
+    const float* __restrict__ ed = edges + (int64_t)n * 3 * kEdgeStride;
+    const bool hx0 = X0 > 0, hx1 = X1 < g.G[0] - 1;
+    const bool hy0 = Y0 > 0, hy1 = Y1 < g.G[1] - 1;
+    const bool hz0 = Z0 > 0, hz1 = Z1 < g.G[2] - 1;
+    float lb = __builtin_inff();
+    if (hx0) lb = fminf(lb, face_bound<NORM>(qx - prev_float(ed[X0])));
+    if (hx1) lb = fminf(lb, face_bound<NORM>(ed[X1 + 1] - qx));
+    if (hy0) lb = fminf(lb, face_bound<NORM>(qy - prev_float(ed[kEdgeStride + Y0])));
+    if (hy1) lb = fminf(lb, face_bound<NORM>(ed[kEdgeStride + Y1 + 1] - qy));
+    if (hz0) lb = fminf(lb, face_bound<NORM>(qz - prev_float(ed[2 * kEdgeStride + Z0])));
+    if (hz1) lb = fminf(lb, face_bound<NORM>(ed[2 * kEdgeStride + Z1 + 1] - qz));
+    const bool whole = !(hx0 || hx1 || hy0 || hy1 || hz0 || hz1);
+    const unsigned kth_bits = top.worst_bits();
+    const bool full = kth_bits < 0x7f800000u;
+    const bool ok = whole || (full && __uint_as_float(kth_bits) < lb);
+    if (active) {
+      if (ok) {
+        const int64_t row = (int64_t)n * P1 + qi;
+        write_row<KC>(top, K, g.len2, idxs + row * K, dists + row * K);
+      } else {
+        const int pos = atomicAdd(fb_count + n, 1);
+        fb_list[(int64_t)n * P1 + pos] = qi;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // pass 6: wave-per-query EXPANDING search for the queries pass 5 could not certify
 // (typically < 1 % of a cloud).  The wave's 64 lanes split the candidate records of
 // the cube of cells [c - r, c + r]^3 around the query's cell (coalesced 16-byte
@@ -1095,6 +1277,20 @@ static void launch_grid_search(const KnnArgs& a, const GridWs& ws, int wgs) {
                      a.idxs, a.dists);
 }
 
+static bool grid_lane_mode() {
+  // POINTOPS_GRID_MODE=block selects the block-shared broadcast search (A/B measurements)
+  const char* e = getenv("POINTOPS_GRID_MODE");
+  return !(e && e[0] == 'b');
+}
+
+template <int D, int KC, int NORM>
+static void launch_grid_lane(const KnnArgs& a, const GridWs& ws, int wgs) {
+  hipLaunchKernelGGL((knn_grid_lane_kernel<D, KC, NORM>), dim3((unsigned)wgs), dim3(kGridWave), 0, a.stream, a.p1,
+                     (const GridCloud*)ws.cloud, (const int*)ws.block_prefix, (const float*)ws.edges,
+                     (const int*)ws.cell_start, (const float4*)ws.sorted, (const int*)ws.qlist, ws.fb_count,
+                     ws.fb_list, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
+}
+
 template <int D, int KC, int NORM>
 static void launch_grid_wave(const KnnArgs& a, const GridWs& ws) {
   hipLaunchKernelGGL((knn_grid_wave_kernel<D, KC, NORM>), dim3(kWaveKernelWgsPerCloud, (unsigned)a.N),
@@ -1107,13 +1303,13 @@ static void launch_grid_wave(const KnnArgs& a, const GridWs& ws) {
 template <int D, int NORM>
 static void dispatch_grid_k(const KnnArgs& a, const GridWs& ws, int wgs) {
   const int K = a.K;
-  if (K <= 1) { launch_grid_search<D, 1, NORM>(a, ws, wgs); launch_grid_wave<D, 1, NORM>(a, ws); }
-  else if (K <= 2) { launch_grid_search<D, 2, NORM>(a, ws, wgs); launch_grid_wave<D, 2, NORM>(a, ws); }
-  else if (K <= 4) { launch_grid_search<D, 4, NORM>(a, ws, wgs); launch_grid_wave<D, 4, NORM>(a, ws); }
-  else if (K <= 8) { launch_grid_search<D, 8, NORM>(a, ws, wgs); launch_grid_wave<D, 8, NORM>(a, ws); }
-  else if (K <= 16) { launch_grid_search<D, 16, NORM>(a, ws, wgs); launch_grid_wave<D, 16, NORM>(a, ws); }
-  else if (K <= 24) { launch_grid_search<D, 24, NORM>(a, ws, wgs); launch_grid_wave<D, 24, NORM>(a, ws); }
-  else { launch_grid_search<D, 32, NORM>(a, ws, wgs); launch_grid_wave<D, 32, NORM>(a, ws); }
+  if (K <= 1) { if (grid_lane_mode()) launch_grid_lane<D, 1, NORM>(a, ws, wgs); else launch_grid_search<D, 1, NORM>(a, ws, wgs); launch_grid_wave<D, 1, NORM>(a, ws); }
+  else if (K <= 2) { if (grid_lane_mode()) launch_grid_lane<D, 2, NORM>(a, ws, wgs); else launch_grid_search<D, 2, NORM>(a, ws, wgs); launch_grid_wave<D, 2, NORM>(a, ws); }
+  else if (K <= 4) { if (grid_lane_mode()) launch_grid_lane<D, 4, NORM>(a, ws, wgs); else launch_grid_search<D, 4, NORM>(a, ws, wgs); launch_grid_wave<D, 4, NORM>(a, ws); }
+  else if (K <= 8) { if (grid_lane_mode()) launch_grid_lane<D, 8, NORM>(a, ws, wgs); else launch_grid_search<D, 8, NORM>(a, ws, wgs); launch_grid_wave<D, 8, NORM>(a, ws); }
+  else if (K <= 16) { if (grid_lane_mode()) launch_grid_lane<D, 16, NORM>(a, ws, wgs); else launch_grid_search<D, 16, NORM>(a, ws, wgs); launch_grid_wave<D, 16, NORM>(a, ws); }
+  else if (K <= 24) { if (grid_lane_mode()) launch_grid_lane<D, 24, NORM>(a, ws, wgs); else launch_grid_search<D, 24, NORM>(a, ws, wgs); launch_grid_wave<D, 24, NORM>(a, ws); }
+  else { if (grid_lane_mode()) launch_grid_lane<D, 32, NORM>(a, ws, wgs); else launch_grid_search<D, 32, NORM>(a, ws, wgs); launch_grid_wave<D, 32, NORM>(a, ws); }
 }
 
 template <int D>
@@ -1145,6 +1341,8 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
   float c;
   int B;
   grid_tuning(a.K, &c, &B);
+  const bool lane_mode = grid_lane_mode();
+  if (lane_mode) B = 1;  // queries sorted by cell
   // histogram buffers (cell_count and blk_count are adjacent) start at zero
   const size_t zero_bytes = (size_t)((char*)ws.cell_start - (char*)ws.cell_count);
   if (hipMemsetAsync(ws.cell_count, 0, zero_bytes, a.stream) != hipSuccess) return check_launch("knn grid memset");
@@ -1154,7 +1352,7 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
                      dim3(kBboxBlock), 0, a.stream, a.p2, a.l2, a.P2, a.D, ws.bbox);
   hipLaunchKernelGGL(grid_setup_kernel, dim3((unsigned)a.N), dim3(kSetupBlock), 0, a.stream, a.p2, a.l1, a.l2,
                      a.P1, a.P2, a.D, c, B, ws);
-  hipLaunchKernelGGL(grid_prefix_kernel, dim3(1), dim3(64), 0, a.stream, ws, (int)a.N);
+  hipLaunchKernelGGL(grid_prefix_kernel, dim3(1), dim3(64), 0, a.stream, ws, (int)a.N, lane_mode ? 1 : 0);
   const int wgs = 256 * 32;  // one wave64 per workgroup, up to 32 waves per CU resident
   switch (a.D) {
     case 1: run_d<1>(a, norm, ws, wgs); break;
