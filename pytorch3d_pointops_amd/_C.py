@@ -15,7 +15,8 @@ import os
 import torch  # must be imported first: loads the process-wide HIP runtime (libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpointops_amd.so")
+# POINTOPS_AMD_LIB: another build of the same library (tools/build_variant.py tuning experiments)
+LIB_PATH = os.environ.get("POINTOPS_AMD_LIB") or os.path.join(_HERE, "lib", "libpointops_amd.so")
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64

@@ -81,6 +81,8 @@ struct GridWs {
   int* fb_list;       // N * P1
   int* fb2_count;     // N          queries the expanding search gave up on (whole-cloud scan)
   int* fb2_list;      // N * P1
+  int* fb3_count;     // N          queries the radius-2 quad search could not certify (expanding search)
+  int* fb3_list;      // N * P1
   unsigned* bbox;     // N * 8: ordered-uint keys of min x,y,z (atomicMin) and max x,y,z (atomicMax)
   int* scan_partial;  // N * 2 * ceil(cell_cap / 4096): per-chunk sums / offsets of the two scans
   int cell_cap;
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     ws.cloud[n] = g;
     ws.fb_count[n] = 0;
     ws.fb2_count[n] = 0;
+    ws.fb3_count[n] = 0;
   }
   __syncthreads();
   if (s_g.use_grid) {
@@ -836,6 +839,14 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
   }
 }
 
+// Candidate threshold seeded from the certification bound lb: only candidates with d < lb can
+// appear in a certified answer (certification needs the KC-th best below lb), so the search may
+// ignore the rest from the first record on.  Distances are non-negative, so bit order = value order.
+__device__ __forceinline__ unsigned seed_threshold(float lb, bool whole) {
+  const unsigned b = __float_as_uint(lb);
+  return whole ? 0x7f800000u : (b > 0u ? b - 1u : 0u);
+}
+
 // ---------------------------------------------------------------------------
 // pass 5 (lane-private form): one query per lane, EVERY lane walks only the 3x3x3 cell cube
 // around its own cell (9 contiguous runs of the sorted array), fetched with per-lane 16-byte
@@ -884,6 +895,23 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
     const float4* __restrict__ sp = sorted + (int64_t)n * P2;
 
+    // rigorous lower bound of every point outside the lane's cube (certification), known
+    // before the walk: it also seeds the candidate threshold, since a query whose KC-th best
+    // is not below it is uncertified whatever the candidates beyond it are
+    const float* __restrict__ ed = edges + (int64_t)n * 3 * kEdgeStride;
+    const bool hx0 = X0 > 0, hx1 = X1 < g.G[0] - 1;
+    const bool hy0 = Y0 > 0, hy1 = Y1 < g.G[1] - 1;
+    const bool hz0 = Z0 > 0, hz1 = Z1 < g.G[2] - 1;
+    float lb = __builtin_inff();
+    if (hx0) lb = fminf(lb, face_bound<NORM>(qx - prev_float(ed[X0])));
+    if (hx1) lb = fminf(lb, face_bound<NORM>(ed[X1 + 1] - qx));
+    if (hy0) lb = fminf(lb, face_bound<NORM>(qy - prev_float(ed[kEdgeStride + Y0])));
+    if (hy1) lb = fminf(lb, face_bound<NORM>(ed[kEdgeStride + Y1 + 1] - qy));
+    if (hz0) lb = fminf(lb, face_bound<NORM>(qz - prev_float(ed[2 * kEdgeStride + Z0])));
+    if (hz1) lb = fminf(lb, face_bound<NORM>(ed[2 * kEdgeStride + Z1 + 1] - qz));
+    const bool whole = !(hx0 || hx1 || hy0 || hy1 || hz0 || hz1);
+    const unsigned thr0 = seed_threshold(lb, whole);
+
     // the lane's 9 runs, own row first (near-first order tightens the thresholds early)
 #pragma unroll
     for (int r = 0; r < kLaneRows; ++r) {
@@ -912,7 +940,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
 
     TopKLex<KC> top;
     top.init();
-    unsigned thr = 0x7f800000u;
+    unsigned thr = thr0;
     int qn = 0;
     auto flush = [&]() {
       unsigned long long qk[kQueueCap];
@@ -929,7 +957,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
       }
       bitonic_merge<KC>(top.key);
       qn = 0;
-      thr = top.worst_bits();
+      thr = min(top.worst_bits(), thr0);
     };
 
     // software pipeline: the loads of group g+1 are issued before group g is processed
@@ -974,7 +1002,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
             s_queue[qn * kGridWave + lane] = TopKLex<KC>::make(d, __float_as_int(c[u].w));
             ++qn;
           }
-        } else if (__float_as_uint(d) <= top.worst_bits()) {
+        } else if (__float_as_uint(d) <= min(top.worst_bits(), thr0)) {
           const unsigned long long key = TopKLex<KC>::make(d, __float_as_int(c[u].w));
           if (key < top.key[KC - 1]) top.insert(key);
         }
@@ -988,8 +1016,112 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     }
     if (kUseQueue) flush();
 
-    // certification against the faces of the lane's own cube
-    const float* __restrict__ ed = edges + (int64_t)n * 3 * kEdgeStride;
+    const unsigned kth_bits = top.worst_bits();
+    const bool full = kth_bits < 0x7f800000u;
+    const bool ok = whole || (full && __uint_as_float(kth_bits) < lb);
+    if (active) {
+      if (ok) {
+        const int64_t row = (int64_t)n * P1 + qi;
+        write_row<KC>(top, K, g.len2, idxs + row * K, dists + row * K);
+      } else {
+        const int pos = atomicAdd(fb_count + n, 1);
+        fb_list[(int64_t)n * P1 + pos] = qi;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 5b: radius-2 search for the queries pass 5 could not certify (~1 % of a cloud).
+// FOUR lanes share a query: the 25 (y, z) rows of the 5x5x5 cell cube around the query's
+// cell are dealt round-robin (nearest rows first) to the quad's lanes, each lane walks its
+// <= 7 contiguous runs exactly like pass 5 (per-lane 16-byte gathers, eight in flight per
+// pipeline stage, stale-threshold queue, sorting-network merges), and two quad-permute
+// exchange steps merge the four sorted lists, after which every lane of the quad holds the
+// cube's KC best.  (8 or 16 lanes per query measured the same within noise: 1.16-1.19 ms
+// per cfg2 step against 1.23 ms without this pass.)  The same rigorous face bound
+// decides; what is still uncertified (far-away queries) goes to the expanding wave search.
+// ---------------------------------------------------------------------------
+#ifndef POINTOPS_QUAD_LANES
+#define POINTOPS_QUAD_LANES 4
+#endif
+#ifndef POINTOPS_QUAD_FETCH
+#define POINTOPS_QUAD_FETCH 8
+#endif
+constexpr int kQuadLanes = POINTOPS_QUAD_LANES;  // lanes per query: 4, 8 or 16
+constexpr int kQuadRows = (25 + kQuadLanes - 1) / kQuadLanes;
+constexpr int kQuadQueries = kGridWave / kQuadLanes;
+constexpr int kQuadFetch = POINTOPS_QUAD_FETCH;  // gathers in flight per lane and pipeline stage: 4 or 8
+__constant__ signed char kQuadDy[32] = {0, 0, 0, -1, 1, -1, -1, 1, 1, 0, 0, -2, 2, -1, 1, -1, 1, -2, -2, 2, 2, -2, -2, 2, 2, 0, 0, 0, 0, 0, 0, 0};
+__constant__ signed char kQuadDz[32] = {0, -1, 1, 0, 0, -1, 1, -1, 1, -2, 2, 0, 0, -2, -2, 2, 2, -1, 1, -1, 1, -2, 2, -2, 2, 0, 0, 0, 0, 0, 0, 0};
+
+// DPP controls: quad_perm [1,0,3,2] (lane ^ 1), quad_perm [2,3,0,1] (lane ^ 2), row_half_mirror
+// (lane -> 7 - lane within 8), row_mirror (lane -> 15 - lane within 16): after steps 1..s every
+// lane of a 2^s group has met a lane of the other half, which already held that half's result
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)v, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, true);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+// merge the partner lane's ascending list into mine: both lanes end with the KC smallest of the union
+template <int KC, int CTRL>
+__device__ __forceinline__ void dpp_merge(TopKLex<KC>& top) {
+  unsigned long long o[KC];
+#pragma unroll
+  for (int t = 0; t < KC; ++t) o[t] = dpp_u64<CTRL>(top.key[t]);
+  if constexpr ((KC & (KC - 1)) == 0 && KC >= 2) {
+#pragma unroll
+    for (int t = 0; t < KC; ++t) {  // min(a[t], o[KC-1-t]) is bitonic and holds the KC smallest
+      const unsigned long long b = o[KC - 1 - t];
+      top.key[t] = b < top.key[t] ? b : top.key[t];
+    }
+    bitonic_merge<KC>(top.key);
+  } else {
+#pragma unroll
+    for (int t = 0; t < KC; ++t) {
+      if (o[t] < top.key[KC - 1]) top.insert(o[t]);
+    }
+  }
+}
+
+template <int D, int KC, int NORM>
+__global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
+    const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const float* __restrict__ edges,
+    const int* __restrict__ cell_start, const float4* __restrict__ sorted, const int* __restrict__ fb_count,
+    const int* __restrict__ fb_list, int* __restrict__ fb3_count, int* __restrict__ fb3_list, int cell_cap, int P1,
+    int P2, int K, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+  constexpr bool kUseQueue = KC >= 8 && (KC & (KC - 1)) == 0;
+  constexpr int kQueueCap = KC < 16 ? KC : 16;
+  constexpr int kSub = 4;
+  static_assert(kQuadFetch % kSub == 0, "fetch groups are processed four candidates at a time");
+  __shared__ unsigned long long s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
+  __shared__ int2 s_rows[kQuadRows][kGridWave];
+
+  const int n = blockIdx.y;
+  const int cnt = fb_count[n];
+  const int lane = threadIdx.x;
+  const int sub = lane & (kQuadLanes - 1);
+  const GridCloud g = clouds[n];
+  const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
+  const float4* __restrict__ sp = sorted + (int64_t)n * P2;
+  const float* __restrict__ ed = edges + (int64_t)n * 3 * kEdgeStride;
+
+  for (int base = blockIdx.x * kQuadQueries; base < cnt; base += gridDim.x * kQuadQueries) {
+    const int w = base + lane / kQuadLanes;
+    const bool active = w < cnt;
+    const int qi = active ? fb_list[(int64_t)n * P1 + w] : 0;
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (active) load_point3<D>(p1 + ((int64_t)n * P1 + qi) * D, qx, qy, qz);
+    int cx, cy, cz;
+    point_cells(g, qx, qy, qz, cx, cy, cz);
+    const int X0 = max(cx - 2, 0), X1 = min(cx + 2, g.G[0] - 1);
+    const int Y0 = max(cy - 2, 0), Y1 = min(cy + 2, g.G[1] - 1);
+    const int Z0 = max(cz - 2, 0), Z1 = min(cz + 2, g.G[2] - 1);
+
     const bool hx0 = X0 > 0, hx1 = X1 < g.G[0] - 1;
     const bool hy0 = Y0 > 0, hy1 = Y1 < g.G[1] - 1;
     const bool hz0 = Z0 > 0, hz1 = Z1 < g.G[2] - 1;
@@ -1001,16 +1133,127 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     if (hz0) lb = fminf(lb, face_bound<NORM>(qz - prev_float(ed[2 * kEdgeStride + Z0])));
     if (hz1) lb = fminf(lb, face_bound<NORM>(ed[2 * kEdgeStride + Z1 + 1] - qz));
     const bool whole = !(hx0 || hx1 || hy0 || hy1 || hz0 || hz1);
+    const unsigned thr0 = seed_threshold(lb, whole);
+
+#pragma unroll
+    for (int j = 0; j < kQuadRows; ++j) {
+      const int rr = sub + kQuadLanes * j;  // table entries >= 25 do not exist
+      const int z = cz + kQuadDz[rr], y = cy + kQuadDy[rr];
+      int2 se = make_int2(0, 0);
+      if (active && rr < 25 && z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1]) {
+        const int rowbase = (z * g.G[1] + y) * g.G[0];
+        se.x = cstart[rowbase + X0];
+        se.y = cstart[rowbase + X1 + 1];
+      }
+      s_rows[j][lane] = se;
+    }
+    int r = 0;
+    int cur = s_rows[0][lane].x, end = s_rows[0][lane].y;
+    auto next_record = [&]() -> int {
+      while (cur >= end && r < kQuadRows - 1) {
+        ++r;
+        const int2 se = s_rows[r][lane];
+        cur = se.x;
+        end = se.y;
+      }
+      return cur < end ? cur++ : -1;
+    };
+
+    TopKLex<KC> top;
+    top.init();
+    unsigned thr = thr0;
+    int qn = 0;
+    auto flush = [&]() {
+      unsigned long long qk[kQueueCap];
+#pragma unroll
+      for (int t = 0; t < kQueueCap; ++t) {
+        const unsigned long long v = s_queue[t * kGridWave + lane];
+        qk[t] = t < qn ? v : TopKLex<KC>::kEmpty;
+      }
+      bitonic_sort<kQueueCap>(qk);
+#pragma unroll
+      for (int t = 0; t < kQueueCap; ++t) {
+        const unsigned long long a = top.key[KC - 1 - t];
+        top.key[KC - 1 - t] = qk[t] < a ? qk[t] : a;
+      }
+      bitonic_merge<KC>(top.key);
+      qn = 0;
+      thr = min(top.worst_bits(), thr0);
+    };
+    auto fetch = [&](float4 (&c)[kQuadFetch]) -> bool {
+      int a[kQuadFetch];
+#pragma unroll
+      for (int u = 0; u < kQuadFetch; ++u) a[u] = next_record();
+#pragma unroll
+      for (int u = 0; u < kQuadFetch; ++u) {
+        const float qnan = __uint_as_float(0x7fc00000u);
+        c[u] = make_float4(qnan, qnan, qnan, 0.f);
+        if (a[u] >= 0) c[u] = sp[a[u]];
+      }
+      return a[0] >= 0;
+    };
+    float4 c[kQuadFetch];
+    bool more = fetch(c);
+    while (__any(more)) {
+      float4 nxt[kQuadFetch];
+      const bool more_next = fetch(nxt);
+#pragma unroll
+      for (int u0 = 0; u0 < kQuadFetch; u0 += kSub) {
+#pragma unroll
+        for (int u = u0; u < u0 + kSub; ++u) {
+          float d;
+          if (NORM == 1) {
+            d = __builtin_fabsf(qx - c[u].x);
+            if (D > 1) d = d + __builtin_fabsf(qy - c[u].y);
+            if (D > 2) d = d + __builtin_fabsf(qz - c[u].z);
+          } else {
+            const float dx = qx - c[u].x;
+            d = dx * dx;
+            if (D > 1) {
+              const float dy = qy - c[u].y;
+              d = d + dy * dy;
+            }
+            if (D > 2) {
+              const float dz = qz - c[u].z;
+              d = d + dz * dz;
+            }
+          }
+          if (kUseQueue) {
+            if (__float_as_uint(d) <= thr) {
+              s_queue[qn * kGridWave + lane] = TopKLex<KC>::make(d, __float_as_int(c[u].w));
+              ++qn;
+            }
+          } else if (__float_as_uint(d) <= min(top.worst_bits(), thr0)) {
+            const unsigned long long key = TopKLex<KC>::make(d, __float_as_int(c[u].w));
+            if (key < top.key[KC - 1]) top.insert(key);
+          }
+        }
+        if (kUseQueue) {
+          if (__any(qn > kQueueCap - kSub)) flush();
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kQuadFetch; ++u) c[u] = nxt[u];
+      more = more_next;
+    }
+    if (kUseQueue) flush();
+
+    // the group's sorted lists -> one, held by every lane of the group
+    dpp_merge<KC, kDppXor1>(top);
+    dpp_merge<KC, kDppXor2>(top);
+    if (kQuadLanes >= 8) dpp_merge<KC, kDppHalfMirror>(top);
+    if (kQuadLanes >= 16) dpp_merge<KC, kDppMirror>(top);
+
     const unsigned kth_bits = top.worst_bits();
     const bool full = kth_bits < 0x7f800000u;
     const bool ok = whole || (full && __uint_as_float(kth_bits) < lb);
-    if (active) {
+    if (active && sub == 0) {
       if (ok) {
         const int64_t row = (int64_t)n * P1 + qi;
         write_row<KC>(top, K, g.len2, idxs + row * K, dists + row * K);
       } else {
-        const int pos = atomicAdd(fb_count + n, 1);
-        fb_list[(int64_t)n * P1 + pos] = qi;
+        const int pos = atomicAdd(fb3_count + n, 1);
+        fb3_list[(int64_t)n * P1 + pos] = qi;
       }
     }
   }
@@ -1036,7 +1279,7 @@ __global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
     const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const float* __restrict__ edges,
     const int* __restrict__ cell_start, const float4* __restrict__ sorted, const int* __restrict__ fb_count,
     const int* __restrict__ fb_list, int* __restrict__ fb2_count, int* __restrict__ fb2_list, int cell_cap,
-    int P1, int P2, int K, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+    int P1, int P2, int K, int r_start, int64_t* __restrict__ idxs, float* __restrict__ dists) {
   __shared__ int s_rowsrc[kWaveKernelBlock / kWave][kWaveRows];
   __shared__ int s_rowoff[kWaveKernelBlock / kWave][kWaveRows + 1];
   const int n = blockIdx.y;
@@ -1060,7 +1303,7 @@ __global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
     int cx, cy, cz;
     point_cells(g, qx, qy, qz, cx, cy, cz);
     bool done = false;
-    for (int r = 2; !done; r *= 2) {
+    for (int r = r_start; !done; r *= 2) {
       const int X0 = max(cx - r, 0), X1 = min(cx + r, g.G[0] - 1);
       const int Y0 = max(cy - r, 0), Y1 = min(cy + r, g.G[1] - 1);
       const int Z0 = max(cz - r, 0), Z1 = min(cz + r, g.G[2] - 1);
@@ -1258,6 +1501,8 @@ static size_t carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, i
   w.fb_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.fb2_count = (int*)take(sizeof(int) * (size_t)N);
   w.fb2_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
+  w.fb3_count = (int*)take(sizeof(int) * (size_t)N);
+  w.fb3_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.bbox = (unsigned*)take(sizeof(unsigned) * (size_t)N * 8);
   w.scan_partial = (int*)take(sizeof(int) * (size_t)N * 2 * (size_t)((cap + kScanChunk - 1) / kScanChunk));
   if (ws) *ws = w;
@@ -1291,13 +1536,28 @@ static void launch_grid_lane(const KnnArgs& a, const GridWs& ws, int wgs) {
                      ws.fb_list, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
 }
 
+static bool grid_quad_mode() {
+  // POINTOPS_GRID_QUAD=0 sends uncertified queries straight to the expanding wave search (A/B measurements)
+  const char* e = getenv("POINTOPS_GRID_QUAD");
+  return !(e && e[0] == '0');
+}
+
 template <int D, int KC, int NORM>
 static void launch_grid_wave(const KnnArgs& a, const GridWs& ws) {
+  const bool quad = grid_quad_mode();
+  if (quad) {
+    int64_t wx = a.P1 / (32 * kQuadQueries);  // a few % of a cloud arrive here
+    wx = wx < 8 ? 8 : wx > 4096 ? 4096 : wx;
+    hipLaunchKernelGGL((knn_grid_quad_kernel<D, KC, NORM>), dim3((unsigned)wx, (unsigned)a.N), dim3(kGridWave), 0,
+                       a.stream, a.p1, (const GridCloud*)ws.cloud, (const float*)ws.edges, (const int*)ws.cell_start,
+                       (const float4*)ws.sorted, (const int*)ws.fb_count, (const int*)ws.fb_list, ws.fb3_count,
+                       ws.fb3_list, ws.cell_cap, a.P1, a.P2, a.K, a.idxs, a.dists);
+  }
   hipLaunchKernelGGL((knn_grid_wave_kernel<D, KC, NORM>), dim3(kWaveKernelWgsPerCloud, (unsigned)a.N),
                      dim3(kWaveKernelBlock), 0, a.stream, a.p1, (const GridCloud*)ws.cloud, (const float*)ws.edges,
-                     (const int*)ws.cell_start, (const float4*)ws.sorted, (const int*)ws.fb_count,
-                     (const int*)ws.fb_list, ws.fb2_count, ws.fb2_list, ws.cell_cap, a.P1, a.P2, a.K, a.idxs,
-                     a.dists);
+                     (const int*)ws.cell_start, (const float4*)ws.sorted,
+                     (const int*)(quad ? ws.fb3_count : ws.fb_count), (const int*)(quad ? ws.fb3_list : ws.fb_list),
+                     ws.fb2_count, ws.fb2_list, ws.cell_cap, a.P1, a.P2, a.K, quad ? 4 : 2, a.idxs, a.dists);
 }
 
 template <int D, int NORM>

@@ -1,0 +1,30 @@
+"""Build a tuning variant of libpointops_amd.so: one translation unit recompiled with extra -D flags,
+the other objects reused from the regular build.  Select it at run time with POINTOPS_AMD_LIB=<path>.
+
+  python tools/build_variant.py lpq4 knn_grid.hip -DPOINTOPS_QUAD_LANES=4 -DPOINTOPS_QUAD_FETCH=4
+  -> pytorch3d_pointops_amd/lib/variants/libpointops_amd_lpq4.so
+"""
+import glob
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from pytorch3d_pointops_amd import build as B  # noqa: E402
+
+
+def main():
+    name, unit, flags = sys.argv[1], sys.argv[2], sys.argv[3:]
+    B.build()
+    out_dir = os.path.join(B.LIB_DIR, "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    obj = os.path.join(B.OBJ_DIR, f"{unit}.{name}.o")
+    subprocess.check_call([B.HIPCC] + B.CXXFLAGS + flags + ["-c", os.path.join(B.CSRC, unit), "-o", obj])
+    objs = [o for o in sorted(glob.glob(os.path.join(B.OBJ_DIR, "*.hip.o"))) if os.path.basename(o) != unit + ".o"]
+    lib = os.path.join(out_dir, f"libpointops_amd_{name}.so")
+    subprocess.check_call([B.HIPCC, f"--offload-arch={B.ARCH}", "-shared", "-fPIC", "-o", lib] + objs + [obj])
+    print(lib)
+
+
+if __name__ == "__main__":
+    main()
