@@ -179,6 +179,37 @@ def test_knn_backward(dev, oracle, name):
     assert np.array_equal(bits(g1), bits(o1)) and close(g2, o2)
 
 
+@pytest.mark.parametrize("mode,split", [("tiled", None), ("tiled", "3"), ("atomic", None)])
+@pytest.mark.parametrize("D,norm", [(3, 2), (3, 1), (2, 2), (4, 2), (1, 2)])
+def test_knn_backward_modes(dev, oracle, monkeypatch, mode, split, D, norm):
+    """grad_p2 through the LDS-tile kernel (several tiles per cloud, ragged clouds, an empty cloud,
+    row splits that meet with atomics) and through the device-atomic kernel: both against the
+    oracle's CPU loop (knn_cpu.cpp:75-128) on the SAME neighbour table."""
+    from pytorch3d_pointops_amd import _C
+
+    monkeypatch.setenv("POINTOPS_KNN_BWD_MODE", mode)
+    if split:
+        monkeypatch.setenv("POINTOPS_KNN_BWD_SPLIT", split)
+    N, P1, P2, K = 3, 2500, 30000, 8
+    p1 = cases.cloud(1500 + D, (N, P1, D))
+    p2 = cases.cloud(1510 + D, (N, P2, D))
+    l1 = np.array([P1, 1777, 0])
+    l2 = np.array([P2, 9001, 5])
+    idx, _ = _C.knn_points_idx(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm, K, -1)
+    grad = cases.grad_for("bwd_modes", (N, P1, K))
+    g1, g2 = _C.knn_points_backward(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), idx, norm, G(grad, dev))
+    o1, o2 = oracle.knn_points_backward(p1, p2, l1, l2, idx.cpu().numpy(), norm, grad)
+    assert np.array_equal(bits(g1.cpu().numpy()), bits(o1))
+    assert close(g2.cpu().numpy(), o2)
+    # ball-query style table: -1 padding and out-of-tile rows are ignored alike
+    idx2 = idx.clone()
+    idx2[:, ::3, 1::2] = -1
+    g1b, g2b = _C.knn_points_backward(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), idx2, norm, G(grad, dev))
+    o1b, o2b = oracle.knn_points_backward(p1, p2, l1, l2, np.where(idx2.cpu().numpy() < 0, 0, idx2.cpu().numpy()), norm,
+                                          np.where(idx2.cpu().numpy() < 0, 0.0, grad).astype(np.float32))
+    assert close(g1b.cpu().numpy(), o1b) and close(g2b.cpu().numpy(), o2b)
+
+
 # ------------------------------------------------------------------ gather
 def test_knn_gather_and_masked_gather(dev):
     from pytorch3d_pointops_amd.functions import knn_gather, masked_gather

@@ -104,8 +104,23 @@ def main():
         Lb = torch.full((Bb,), Pb, dtype=torch.int64, device=dev)
         idx, _ = _C.knn_points_idx(a, c, Lb, Lb, 2, Kb, -1)
         gd = torch.from_numpy(synth.uniform_f32(83, (Bb, Pb, Kb))).to(dev)
-        ms, mn = timeit(lambda: _C.knn_points_backward(a, c, Lb, Lb, idx, 2, gd))
-        emit("knn_points_backward B=32 N=65536 K=16", ms, mn, atomics_per_s=Bb * Pb * Kb * 3 / ms * 1e3)
+        algo = Bb * Pb * Kb * (8 + 4) + 3 * Bb * Pb * 12 + Bb * Pb * 12  # idx + grad_dists, p1/p2 reads + 2 grads
+        for mode in ("tiled", "atomic"):
+            os.environ["POINTOPS_KNN_BWD_MODE"] = mode
+            ms, mn = timeit(lambda: _C.knn_points_backward(a, c, Lb, Lb, idx, 2, gd))
+            emit(f"knn_points_backward B=32 N=65536 K=16 [{mode}]", ms, mn, algo_GBs=algo / ms / 1e6,
+                 scatter_adds_per_s=Bb * Pb * Kb * 3 / ms * 1e3)
+        del os.environ["POINTOPS_KNN_BWD_MODE"]
+        for (b, n, k) in ((1, 65536, 16), (4, 16384, 16), (8, 65536, 1)):
+            a2, c2 = a[:b, :n].contiguous(), c[:b, :n].contiguous()
+            L2 = torch.full((b,), n, dtype=torch.int64, device=dev)
+            idx2, _ = _C.knn_points_idx(a2, c2, L2, L2, 2, k, -1)
+            gd2 = gd[:b, :n, :k].contiguous()
+            for mode in ("tiled", "atomic"):
+                os.environ["POINTOPS_KNN_BWD_MODE"] = mode
+                ms, mn = timeit(lambda: _C.knn_points_backward(a2, c2, L2, L2, idx2, 2, gd2))
+                emit(f"knn_points_backward B={b} N={n} K={k} [{mode}]", ms, mn)
+            del os.environ["POINTOPS_KNN_BWD_MODE"]
     if "knn_small" in ops:
         for (b, n, k) in ((2, 1024, 8), (32, 4096, 16), (8, 65536, 1)):
             a = torch.from_numpy(synth.uniform_f32(71, (b, n, 3))).to(dev)
