@@ -6,8 +6,10 @@
 // reference builds this from expand + torch.gather, which materialises an
 // (N,L,K,U) int64 index (8*U bytes per output element); here the index is read
 // once per (n,l,k) row and the output is written coalesced, one lane per element.
-// Backward scatters grad_out into grad_x with fp32 atomics (same masks).
+// Backward scatters grad_out into grad_x (same masks): LDS tiles without device atomics
+// (tiled_scatter.h) when U <= 4 and the table is large, fp32 device atomics otherwise.
 #include "common.h"
+#include "tiled_scatter.h"
 
 namespace pointops {
 
@@ -51,6 +53,26 @@ __global__ __launch_bounds__(kGaBlock) void gather_backward_kernel(
   }
 }
 
+// addend of entry (l, k) -> row j: grad_out[n, l, k, :]
+template <int C>
+struct GatherGradSrc {
+  static constexpr int kChannels = C;
+  struct Regs {
+    float v[C];
+  };
+  const float* grad_out;
+  const int64_t* lengths;  // may be null
+  int L, K;
+  __device__ int rows(int) const { return L; }
+  __device__ int kmax(int n) const { return lengths != nullptr ? (int)min((int64_t)K, max((int64_t)0, lengths[n])) : K; }
+  __device__ void issue(int n, int e, int, int, int, Regs& r) const {
+    const float* __restrict__ g = grad_out + ((int64_t)n * L * K + e) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) r.v[c] = g[c];
+  }
+  __device__ float value(const Regs& r, int c) const { return r.v[c]; }
+};
+
 }  // namespace pointops
 
 using namespace pointops;
@@ -76,12 +98,28 @@ extern "C" int pointops_gather_neighbors_backward(const float* grad_out, const i
   POINTOPS_REQUIRE(N >= 0 && M >= 0 && U >= 1 && L >= 0 && K >= 0 && U < (1LL << 31) && K < (1LL << 31),
                    "gather_neighbors_backward: bad sizes");
   hipStream_t stream = (hipStream_t)stream_;
-  if (N * M * U > 0) {
+  const TiledPlan plan = tiled_plan(N, L, K, M, (int)U, "POINTOPS_GATHER_BWD_MODE", "POINTOPS_GATHER_BWD_SPLIT");
+  if (N * M * U > 0 && !(plan.tiled && plan.S == 1)) {
     if (hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)(N * M * U), stream) != hipSuccess)
       return check_launch("gather_neighbors_backward(memset)");
   }
   const int64_t total = N * L * K * U;
   if (total == 0) return POINTOPS_OK;
+  if (plan.tiled) {
+    const DivMagic dm = division_magic((unsigned)K);
+#define PO_TILED(C)                                                                                          \
+  do {                                                                                                       \
+    const GatherGradSrc<C> src{grad_out, lengths, (int)L, (int)K};                                           \
+    hipLaunchKernelGGL((tiled_scatter_kernel<GatherGradSrc<C>>), plan.grid, dim3(kTiledBlock), 0, stream,    \
+                       src, idx, (int)N, (int)L, (int)M, (int)K, dm, plan.parts, plan.S, grad_x);            \
+  } while (0)
+    if (U == 1) PO_TILED(1);
+    else if (U == 2) PO_TILED(2);
+    else if (U == 3) PO_TILED(3);
+    else PO_TILED(4);
+#undef PO_TILED
+    return check_launch("gather_neighbors_backward(tiled)");
+  }
   const int64_t blocks = ceil_div(total, kGaBlock);
   POINTOPS_REQUIRE(blocks < (1LL << 31), "gather_neighbors_backward: grid too large");
   hipLaunchKernelGGL(gather_backward_kernel, dim3((unsigned)blocks), dim3(kGaBlock), 0, stream,

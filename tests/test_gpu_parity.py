@@ -210,6 +210,34 @@ def test_knn_backward_modes(dev, oracle, monkeypatch, mode, split, D, norm):
     assert close(g1b.cpu().numpy(), o1b) and close(g2b.cpu().numpy(), o2b)
 
 
+@pytest.mark.parametrize("mode,split", [("tiled", None), ("tiled", "2"), ("atomic", None)])
+@pytest.mark.parametrize("U", [1, 3, 4])
+def test_gather_backward_modes(dev, monkeypatch, mode, split, U):
+    """knn_gather / masked_gather backward (scatter-add of grad_out rows into grad_x) through the
+    LDS-tile kernel and the device-atomic kernel against a float64 np.add.at of the same masks
+    (functions/knn.py:236-248: k >= lengths[n] zeroed; utils.py:53-63: -1 rows zeroed)."""
+    from pytorch3d_pointops_amd import _C, synth
+
+    monkeypatch.setenv("POINTOPS_GATHER_BWD_MODE", mode)
+    if split:
+        monkeypatch.setenv("POINTOPS_GATHER_BWD_SPLIT", split)
+    N, L, K, M = 2, 3000, 8, 20000
+    idx = synth.randint(1601, -1, M - 1, (N, L, K))
+    idx[0, ::7, :] = 3  # many rows onto one target row
+    go = cases.grad_for("gbm%d" % U, (N, L, K, U))
+    go[1, 5::11] = 0.0
+    for lengths in (None, np.array([8, 5])):
+        gx = _C.gather_neighbors_backward(G(go, dev), G(idx, dev), None if lengths is None else G(lengths, dev), M)
+        ref = np.zeros((N, M, U), np.float64)
+        for n in range(N):
+            kk = K if lengths is None else int(lengths[n])
+            ii = idx[n, :, :kk].reshape(-1)
+            vv = go[n, :, :kk].reshape(-1, U).astype(np.float64)
+            ok = ii >= 0
+            np.add.at(ref[n], ii[ok], vv[ok])
+        assert close(gx.cpu().numpy(), ref)
+
+
 # ------------------------------------------------------------------ gather
 def test_knn_gather_and_masked_gather(dev):
     from pytorch3d_pointops_amd.functions import knn_gather, masked_gather

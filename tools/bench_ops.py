@@ -97,6 +97,14 @@ def main():
         ig = torch.from_numpy(synth.randint(62, 0, Pg - 1, (Bg, Pg, Kg))).to(dev)
         ms, mn = timeit(lambda: knn_gather(xg, ig))
         emit("knn_gather B=32 N=65536 K=16 U=3", ms, mn, algo_GBs=(Bg * Pg * Kg * (8 + 12) + Bg * Pg * 12) / ms / 1e6)
+    if "gather" in ops:
+        gg = torch.from_numpy(synth.uniform_f32(63, (Bg, Pg, Kg, 3))).to(dev)
+        for mode in ("tiled", "atomic"):
+            os.environ["POINTOPS_GATHER_BWD_MODE"] = mode
+            ms, mn = timeit(lambda: _C.gather_neighbors_backward(gg, ig, None, Pg))
+            emit(f"knn_gather backward B=32 N=65536 K=16 U=3 [{mode}]", ms, mn,
+                 algo_GBs=(Bg * Pg * Kg * (8 + 12) + Bg * Pg * 12) / ms / 1e6)
+        del os.environ["POINTOPS_GATHER_BWD_MODE"]
     if "knn_bwd" in ops:
         Bb, Pb, Kb = 32, 65536, 16
         a = torch.from_numpy(synth.uniform_f32(81, (Bb, Pb, 3))).to(dev)
