@@ -24,6 +24,9 @@
 //     bench sizes); all workgroups of a cloud re-stream the same 12*P2 bytes,
 //     which stay L2/Infinity-Cache resident (786 KB per cloud at P2=65536).
 #include "knn_common.h"
+
+#include <algorithm>
+#include <cstdlib>
 #include "knn_grid.h"
 
 namespace pointops {
@@ -38,11 +41,12 @@ template <int D, int KC, int NORM>
 __global__ __launch_bounds__(kKnnBlock) void knn_reg_kernel(
     const float* __restrict__ p1, const float* __restrict__ p2,
     const int64_t* __restrict__ lengths1, const int64_t* __restrict__ lengths2, int P1, int P2,
-    int K, int tiles_per_cloud, const int* __restrict__ qlist, const int* __restrict__ qcount,
-    int64_t* __restrict__ idxs, float* __restrict__ dists) {
+    int K, int tiles_per_cloud, const int* __restrict__ qlist, const int* __restrict__ qcount, int S,
+    unsigned long long* __restrict__ partial, int64_t* __restrict__ idxs, float* __restrict__ dists) {
   const int n = blockIdx.x / tiles_per_cloud;  // wave-uniform
   const int tile = blockIdx.x - n * tiles_per_cloud;
-  int i = tile * kKnnBlock + threadIdx.x;
+  const int split = blockIdx.y;  // slice of p2 (S > 1: partial lists, merged by knn_merge_kernel)
+  int i = tile * (int)blockDim.x + threadIdx.x;  // 256 lanes, or 64 for small batches
   int len2 = (int)lengths2[n];
   if (len2 > P2) len2 = P2;
   if (len2 < 0) len2 = 0;
@@ -52,6 +56,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_reg_kernel(
   } else {
     if (i >= P1) return;
     if (i >= (int)lengths1[n]) {  // padded query row: zeros (knn_cpu.cpp:25-26)
+      if (S > 1) return;          // the merge pass writes the row
       int64_t* __restrict__ zi = idxs + ((int64_t)n * P1 + i) * K;
       float* __restrict__ zd = dists + ((int64_t)n * P1 + i) * K;
       for (int k = 0; k < K; ++k) {
@@ -67,8 +72,48 @@ __global__ __launch_bounds__(kKnnBlock) void knn_reg_kernel(
   for (int d = 0; d < D; ++d) a[d] = p1[row * D + d];
   TopK<KC> top;
   top.init();
-  scan_cloud<D, KC, NORM>(a, p2 + (int64_t)n * P2 * D, len2, top);
-  write_row<KC>(top, K, len2, idxs + row * K, dists + row * K);
+  if (S == 1) {
+    scan_cloud<D, KC, NORM>(a, p2 + (int64_t)n * P2 * D, 0, len2, top);
+    write_row<KC>(top, K, len2, idxs + row * K, dists + row * K);
+    return;
+  }
+  const int jbeg = (int)((int64_t)len2 * split / S), jend = (int)((int64_t)len2 * (split + 1) / S);
+  scan_cloud<D, KC, NORM>(a, p2 + (int64_t)n * P2 * D, jbeg, jend, top);
+  // partial list of this slice as (dist bits, idx) keys; empty slots order last
+  unsigned long long* __restrict__ o = partial + (row * S + split) * K;
+  const int have = min(K, jend - jbeg);
+#pragma unroll
+  for (int k = 0; k < KC; ++k)
+    if (k < K) o[k] = k < have ? TopKLex<KC>::make(top.dk[k], top.ik[k]) : TopKLex<KC>::kEmpty;
+}
+
+// merge of the S partial lists of a query (each ascending, slices in index order): one lane per
+// query, 64-bit lexicographic keys, early exit per list at the first key that cannot enter
+template <int KC>
+__global__ __launch_bounds__(256) void knn_merge_kernel(
+    const unsigned long long* __restrict__ partial, const int64_t* __restrict__ lengths1,
+    const int64_t* __restrict__ lengths2, int P1, int P2, int K, int S, int64_t total, int64_t* __restrict__ idxs,
+    float* __restrict__ dists) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= total) return;
+  const int n = (int)(row / P1), i = (int)(row - (int64_t)n * P1);
+  int len2 = (int)lengths2[n];
+  if (len2 > P2) len2 = P2;
+  if (len2 < 0) len2 = 0;
+  const bool live = i < (int)lengths1[n];
+  TopKLex<KC> top;
+  top.init();
+  if (live) {
+    for (int s = 0; s < S; ++s) {
+      const unsigned long long* __restrict__ src = partial + (row * S + s) * K;
+      for (int k = 0; k < K; ++k) {
+        const unsigned long long key = src[k];
+        if (!(key < top.key[KC - 1])) break;
+        top.insert(key);
+      }
+    }
+  }
+  write_row<KC>(top, K, live ? len2 : 0, idxs + row * K, dists + row * K);
 }
 
 // ---------------------------------------------------------------------------
@@ -127,43 +172,93 @@ __global__ __launch_bounds__(kKnnBlock) void knn_generic_kernel(
 // ---------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------
+struct RegLaunch {
+  int block, tiles, S;
+  unsigned long long* partial;
+};
+
 template <int D, int KC, int NORM>
-static void launch_reg(const KnnArgs& a) {
-  const dim3 grid((unsigned)(a.N * a.tiles));
-  hipLaunchKernelGGL((knn_reg_kernel<D, KC, NORM>), grid, dim3(kKnnBlock), 0, a.stream, a.p1, a.p2,
-                     a.l1, a.l2, a.P1, a.P2, a.K, a.tiles, a.qlist, a.qcount, a.idxs, a.dists);
+static void launch_reg(const KnnArgs& a, const RegLaunch& r) {
+  const dim3 grid((unsigned)(a.N * r.tiles), (unsigned)r.S);
+  hipLaunchKernelGGL((knn_reg_kernel<D, KC, NORM>), grid, dim3(r.block), 0, a.stream, a.p1, a.p2, a.l1, a.l2, a.P1,
+                     a.P2, a.K, r.tiles, a.qlist, a.qcount, r.S, r.partial, a.idxs, a.dists);
 }
 
 template <int D, int NORM>
-static void dispatch_k(const KnnArgs& a) {
+static void dispatch_k(const KnnArgs& a, const RegLaunch& r) {
   const int K = a.K;
-  if (K <= 1) launch_reg<D, 1, NORM>(a);
-  else if (K <= 2) launch_reg<D, 2, NORM>(a);
-  else if (K <= 4) launch_reg<D, 4, NORM>(a);
-  else if (K <= 8) launch_reg<D, 8, NORM>(a);
-  else if (K <= 16) launch_reg<D, 16, NORM>(a);
-  else if (K <= 24) launch_reg<D, 24, NORM>(a);
-  else launch_reg<D, 32, NORM>(a);
+  if (K <= 1) launch_reg<D, 1, NORM>(a, r);
+  else if (K <= 2) launch_reg<D, 2, NORM>(a, r);
+  else if (K <= 4) launch_reg<D, 4, NORM>(a, r);
+  else if (K <= 8) launch_reg<D, 8, NORM>(a, r);
+  else if (K <= 16) launch_reg<D, 16, NORM>(a, r);
+  else if (K <= 24) launch_reg<D, 24, NORM>(a, r);
+  else launch_reg<D, 32, NORM>(a, r);
 }
 
 template <int NORM>
-static void dispatch_d(const KnnArgs& a) {
+static void dispatch_d(const KnnArgs& a, const RegLaunch& r) {
   switch (a.D) {
-    case 1: dispatch_k<1, NORM>(a); break;
-    case 2: dispatch_k<2, NORM>(a); break;
-    case 3: dispatch_k<3, NORM>(a); break;
-    case 4: dispatch_k<4, NORM>(a); break;
-    case 5: dispatch_k<5, NORM>(a); break;
-    case 6: dispatch_k<6, NORM>(a); break;
-    case 7: dispatch_k<7, NORM>(a); break;
-    case 8: dispatch_k<8, NORM>(a); break;
+    case 1: dispatch_k<1, NORM>(a, r); break;
+    case 2: dispatch_k<2, NORM>(a, r); break;
+    case 3: dispatch_k<3, NORM>(a, r); break;
+    case 4: dispatch_k<4, NORM>(a, r); break;
+    case 5: dispatch_k<5, NORM>(a, r); break;
+    case 6: dispatch_k<6, NORM>(a, r); break;
+    case 7: dispatch_k<7, NORM>(a, r); break;
+    case 8: dispatch_k<8, NORM>(a, r); break;
     default: break;
   }
 }
 
-void launch_knn_bruteforce(const KnnArgs& a, int norm) {
-  if (norm == 1) dispatch_d<1>(a);
-  else dispatch_d<2>(a);
+int knn_split_count(int64_t N, int64_t P1, int64_t P2, int64_t K) {
+  if (K > 32) return 1;
+  const int64_t waves = N * ceil_div(P1, 64);
+  if (waves >= 2048 || P2 < 512) return 1;
+  int64_t s = ceil_div(4096, waves);
+  s = std::min<int64_t>(s, 8);
+  s = std::min<int64_t>(s, P2 / 256);  // a slice keeps >= 256 candidates
+  return (int)std::max<int64_t>(s, 1);
+}
+
+size_t knn_split_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K) {
+  const int S = knn_split_count(N, P1, P2, K);
+  return S > 1 ? sizeof(unsigned long long) * (size_t)(N * P1 * S * K) : 0;
+}
+
+void knn_merge_partials(const KnnArgs& a, int S, const void* workspace) {
+  const int64_t total = a.N * a.P1;
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  const unsigned long long* ws = (const unsigned long long*)workspace;
+#define PO_MERGE(KC)                                                                                              \
+  hipLaunchKernelGGL(knn_merge_kernel<KC>, grid, block, 0, a.stream, ws, a.l1, a.l2, a.P1, a.P2, a.K, S, total, \
+                     a.idxs, a.dists)
+  const int K = a.K;
+  if (K <= 1) PO_MERGE(1);
+  else if (K <= 2) PO_MERGE(2);
+  else if (K <= 4) PO_MERGE(4);
+  else if (K <= 8) PO_MERGE(8);
+  else if (K <= 16) PO_MERGE(16);
+  else if (K <= 24) PO_MERGE(24);
+  else PO_MERGE(32);
+#undef PO_MERGE
+}
+
+void launch_knn_bruteforce(const KnnArgs& a, int norm, void* workspace) {
+  // small batches: 64-lane workgroups (4x as many) and p2 slices; the query-list mode of the grid
+  // fallback always scans whole clouds
+  RegLaunch r{kKnnBlock, a.tiles, 1, nullptr};
+  if (a.qlist == nullptr && a.N * a.tiles < 2048) {
+    r.block = 64;
+    r.tiles = (int)ceil_div(a.P1, 64);
+    if (workspace != nullptr) {
+      r.S = knn_split_count(a.N, a.P1, a.P2, a.K);
+      r.partial = (unsigned long long*)workspace;
+    }
+  }
+  if (norm == 1) dispatch_d<1>(a, r);
+  else dispatch_d<2>(a, r);
+  if (r.S > 1) knn_merge_partials(a, r.S, workspace);
 }
 
 }  // namespace pointops
@@ -175,7 +270,8 @@ extern "C" {
 int pointops_knn_check_version(int version, int64_t D, int64_t K) {
   // Kernel families of this library.  As in the reference (csrc/knn/knn.cu:292-312) the
   // highest valid version is the fastest and `version` never changes results:
-  //   0 generic (any D, any K; list kept in the output rows)
+  //   0 any D, any K: LDS-transposed queries with register (K <= 32) or LDS lists (knn_wide.hip);
+  //     beyond the LDS budget the plain generic kernel (list kept in the output rows)
   //   1, 2 register top-K brute-force scan (D in [1,8], K in [1,32])
   //   3 exact grid-pruned search + brute-force fallback (D in [1,3], K in [1,32])
   if (version == 0) return 1;
@@ -188,9 +284,14 @@ static int choose_version(int version, int64_t N, int64_t P1, int64_t P2, int64_
   const bool grid_ok = pointops_knn_check_version(3, D, K) && P2 <= (1LL << 20);  // scan chunk table limit
   if (version == 3 && !grid_ok) version = -1;
   if (version >= 0 && version <= 3 && pointops_knn_check_version(version, D, K)) return version;
-  // auto: the grid only pays once the all-pairs scan is long enough to amortise its
-  // (sort + scan) passes; below that the brute-force scan is latency-optimal.
-  if (grid_ok && P2 >= 4096 && P1 * P2 >= (1LL << 24)) return 3;
+  // auto: the grid only pays once the all-pairs scan is long enough to amortise its ~15 launches
+  // (sort + scan passes, ~0.15-0.3 ms); below that the sliced brute-force scan is faster.  The
+  // crossover in total pairs grows as K shrinks, because short lists make the scan cheap per pair
+  // (measured v2 against v3, N = 1..32 clouds of 4096..32768 points, profiles/r01_knn_crossover.txt).
+  const double pairs = (double)N * (double)P1 * (double)P2;
+  const double cross = K <= 2 ? 1.5 * (double)(1LL << 29) : K <= 4 ? (double)(1LL << 29) : K <= 8 ? (double)(1LL << 28)
+                       : K <= 16 ? (double)(1LL << 27) : (double)(1LL << 24);
+  if (grid_ok && P2 >= 4096 && pairs >= cross) return 3;
   if (pointops_knn_check_version(2, D, K)) return 2;
   return 0;
 }
@@ -198,7 +299,9 @@ static int choose_version(int version, int64_t N, int64_t P1, int64_t P2, int64_
 size_t pointops_knn_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K,
                                     int version) {
   if (N <= 0 || P1 <= 0 || D < 1 || K < 1) return 0;
-  if (choose_version(version, N, P1, P2, D, K) != 3) return 0;
+  const int v = choose_version(version, N, P1, P2, D, K);
+  if (v == 0 && !knn_wide_supported(D, K)) return 0;
+  if (v != 3) return knn_split_workspace_bytes(N, P1, P2, K);
   return knn_grid_workspace_bytes(N, P1, P2, K);
 }
 
@@ -232,6 +335,15 @@ int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* len
     }
     const int rc = knn_grid_run(a, norm, workspace);
     if (rc != POINTOPS_OK) return rc;
+  } else if (v == 0 && knn_wide_supported(D, K) && !getenv("POINTOPS_KNN_GENERIC")) {
+    // any D / long lists: LDS-transposed queries (POINTOPS_KNN_GENERIC=1 keeps the plain fallback, tests)
+    const size_t need = knn_split_workspace_bytes(N, P1, P2, K);
+    if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {
+      set_error("knn_points_idx: workspace of %zu bytes required (got %zu)", need, workspace_bytes);
+      return POINTOPS_EWORKSPACE;
+    }
+    const int rc = launch_knn_wide(a, norm, workspace);
+    if (rc != POINTOPS_OK) return rc;
   } else if (v == 0) {
     const dim3 grid((unsigned)(N * a.tiles));
     if (norm == 1)
@@ -241,7 +353,8 @@ int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* len
       hipLaunchKernelGGL(knn_generic_kernel<2>, grid, dim3(kKnnBlock), 0, a.stream, p1, p2, lengths1,
                          lengths2, a.P1, a.P2, a.D, a.K, a.tiles, idxs, dists);
   } else {
-    launch_knn_bruteforce(a, norm);
+    const size_t need = knn_split_workspace_bytes(N, P1, P2, K);
+    launch_knn_bruteforce(a, norm, workspace != nullptr && workspace_bytes >= need && need > 0 ? workspace : nullptr);
   }
   return check_launch("knn_points_idx");
 }

@@ -99,9 +99,9 @@ struct TopKLex {
 // points are consumed as SGPR operands.
 // ---------------------------------------------------------------------------
 template <int D, int KC, int NORM>
-__device__ __forceinline__ void scan_cloud(const float (&a)[D], const float* __restrict__ q, int len2,
-                                           TopK<KC>& top) {
-  int j = 0;
+__device__ __forceinline__ void scan_cloud(const float (&a)[D], const float* __restrict__ q, int jbeg, int len2,
+                                           TopK<KC>& top) {  // rows [jbeg, len2) of the cloud at q
+  int j = jbeg;
   for (; j + kTileP2 <= len2; j += kTileP2) {
     float t[kTileP2 * D];
 #pragma unroll

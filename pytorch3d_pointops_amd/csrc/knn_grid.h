@@ -17,8 +17,19 @@ struct KnnArgs {
   hipStream_t stream;
 };
 
-// brute-force register-top-K scan (knn.hip); honours a.qlist / a.qcount
-void launch_knn_bruteforce(const KnnArgs& a, int norm);
+// brute-force register-top-K scan (knn.hip); honours a.qlist / a.qcount.  With `workspace` (of
+// knn_split_workspace_bytes) a small batch is scanned in p2 slices and merged (knn_split_count > 1).
+void launch_knn_bruteforce(const KnnArgs& a, int norm, void* workspace = nullptr);
+
+// p2 slices per query so that a small batch still fills the chip (1024 SIMDs): S partial lists per
+// query (64-bit (dist, idx) keys) are merged by knn_merge_partials
+int knn_split_count(int64_t N, int64_t P1, int64_t P2, int64_t K);
+size_t knn_split_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K);
+void knn_merge_partials(const KnnArgs& a, int S, const void* workspace);
+
+// brute-force scan for any D / long lists (knn_wide.hip): LDS-transposed queries, register or LDS lists
+bool knn_wide_supported(int64_t D, int64_t K);
+int launch_knn_wide(const KnnArgs& a, int norm, void* workspace);
 
 // exact grid search (knn_grid.hip)
 size_t knn_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K);

@@ -118,6 +118,43 @@ def _grid_adversarial_cases():
     return c
 
 
+_WIDE = {  # name: (N, P1, P2, D, K, norm, l1, l2)
+    "d64_k20": (2, 300, 700, 64, 20, 2, [300, 123], [700, 650]),
+    "d33_k5_l1": (2, 260, 515, 33, 5, 1, [260, 1], [515, 3]),
+    "d16_k64": (2, 130, 400, 16, 64, 2, [130, 77], [400, 50]),  # K > len2 for cloud 1
+    "d3_k100": (3, 200, 1000, 3, 100, 2, [200, 0, 64], [1000, 900, 0]),
+    "d9_k16": (1, 515, 1030, 9, 16, 2, [515], [1030]),
+    "d3_k33": (2, 200, 3000, 3, 33, 2, [200, 150], [3000, 40]),
+    "d70_k48_l1": (1, 100, 600, 70, 48, 1, [100], [600]),
+    "d3_k64_lattice": (1, 150, 2000, 3, 64, 2, [150], [2000]),
+    "d128_k32": (1, 70, 300, 128, 32, 2, [70], [300]),
+    "d3_k300_lds_cap": (1, 64, 700, 3, 300, 2, [64], [700]),
+    "d200_k4_generic": (1, 40, 90, 200, 4, 2, [40], [77]),  # beyond the LDS budget -> plain generic kernel
+}
+
+
+@pytest.mark.parametrize("name", sorted(_WIDE))
+def test_knn_wide_shapes(dev, oracle, monkeypatch, name):
+    """Feature-space D and long lists (knn_wide.hip: LDS-transposed queries, register or LDS lists),
+    bit-exact against the oracle, and identical to the plain generic kernel."""
+    from pytorch3d_pointops_amd import _C
+
+    N, P1, P2, D, K, norm, l1, l2 = _WIDE[name]
+    p1 = cases.cloud(1700 + D, (N, P1, D))
+    p2 = cases.cloud(1701 + D + K, (N, P2, D))
+    if name in ("d3_k100", "d3_k64_lattice"):
+        p2 = cases.lattice(1702, N, P2, D, levels=5)  # many exact ties inside long lists
+        p1 = cases.lattice(1703, N, P1, D, levels=5)
+    l1, l2 = np.array(l1), np.array(l2)
+    idx, dists = _C.knn_points_idx(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm, K, -1)
+    oi, od = oracle.knn_points_idx(p1, p2, l1, l2, norm, K)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(bits(dists.cpu().numpy()), bits(od))
+    monkeypatch.setenv("POINTOPS_KNN_GENERIC", "1")
+    idx2, dists2 = _C.knn_points_idx(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm, K, 0)
+    assert torch.equal(idx, idx2) and torch.equal(dists.view(torch.int32), dists2.view(torch.int32))
+
+
 @pytest.mark.parametrize("name", sorted(_grid_adversarial_cases()))
 def test_knn_grid_adversarial(dev, oracle, name):
     """Grid search vs the CPU oracle on distributions that stress the bound / fallback logic,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Exhaustive 0-1-principle check of the comparator tables in csrc/knn_grid.hip (SortNet<16>, SortNet<8>)."""
+"""Exhaustive 0-1-principle check of the comparator tables in csrc/sort_net.h (SortNet<16>, SortNet<8>)."""
 import re, sys, os
-src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch3d_pointops_amd", "csrc", "knn_grid.hip")).read()
+src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch3d_pointops_amd", "csrc", "sort_net.h")).read()
 def table(name, n):
     start = src.index("struct SortNet<%d> {" % n)
     m = src[start:src.index("template <int N>\n__device__ __forceinline__ void bitonic_sort", start)]
