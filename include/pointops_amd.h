@@ -95,10 +95,16 @@ int pointops_knn_points_backward(const float* p1, const float* p2, const int64_t
  * (reference: csrc/ball_query/ball_query.h:62-93, ball_query_cpu.cpp:12-54).
  *   First K points of p2 (index order) with dist2 < radius*radius (fp32 product,
  *   strict); idxs padded with -1, dists with 0.
+ *   With a `workspace` of pointops_ball_query_workspace_bytes() (0 = not useful for the shape;
+ *   workspace may then be NULL) clouds whose balls are SPARSE are answered through a cell grid
+ *   instead of the index-order scan; the choice is made per cloud on the device and never changes
+ *   results.  Without workspace every cloud is scanned.
  */
+size_t pointops_ball_query_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K);
 int pointops_ball_query(const float* p1, const float* p2, const int64_t* lengths1,
                         const int64_t* lengths2, int64_t N, int64_t P1, int64_t P2, int64_t D,
-                        int64_t K, float radius, int64_t* idxs, float* dists, void* stream);
+                        int64_t K, float radius, int64_t* idxs, float* dists, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /*
  * Farthest point sampling -- replaces `_C.sample_farthest_points`

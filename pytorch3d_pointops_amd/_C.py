@@ -36,8 +36,9 @@ _SIGNATURES = {
     "pointops_knn_grid_fallback_counts": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "pointops_knn_points_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                             _i64, _int, _vp, _vp, _vp]),
-    "pointops_ball_query": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _vp, _vp,
-                                   _vp]),
+    "pointops_ball_query_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
+    "pointops_ball_query": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _sz,
+                                  _vp]),
     "pointops_fps_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "pointops_sample_farthest_points": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp,
                                                _sz, _vp]),
@@ -213,10 +214,13 @@ def ball_query(p1, p2, lengths1, lengths2, K: int, radius: float):
     with torch.cuda.device(dev):
         idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
         dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
+        ws_bytes = _lib.pointops_ball_query_workspace_bytes(N, P1, P2, D, int(K))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
         _check(
             _lib.pointops_ball_query(p1.data_ptr(), p2.data_ptr(), lengths1.data_ptr(),
                                      lengths2.data_ptr(), N, P1, P2, D, int(K), float(radius),
-                                     idxs.data_ptr(), dists.data_ptr(), _stream()),
+                                     idxs.data_ptr(), dists.data_ptr(),
+                                     ws.data_ptr() if ws is not None else None, ws_bytes, _stream()),
             "ball_query",
         )
     return idxs, dists

@@ -10,7 +10,17 @@
 // scanning as soon as all of its 64 queries are full (wave-uniform early exit via
 // ballot), which on dense clouds is after ~1 % of p2: the
 // op is then bound by writing the (N,P1,K) outputs.
+//
+// SPARSE balls (few points inside the radius: the scan would walk most of the cloud for every
+// query) go through the cell grid of knn_grid.hip instead when the caller provides the
+// workspace: `ball_grid_lane_kernel` answers every query whose 3x3x3 cell cube provably contains
+// its ball; per cloud the choice between grid and scan is made ON THE DEVICE from the bounding box
+// (expected points per ball), and this kernel then scans only what is left: whole clouds whose
+// flag is 0, and the listed (uncertified) queries of the others.
 #include "common.h"
+#include "knn_grid.h"
+
+#include <cstdlib>
 
 namespace pointops {
 
@@ -21,13 +31,19 @@ template <int DT>
 __global__ __launch_bounds__(kBqBlock) void ball_query_kernel(
     const float* __restrict__ p1, const float* __restrict__ p2,
     const int64_t* __restrict__ lengths1, const int64_t* __restrict__ lengths2, int P1, int P2,
-    int Drt, int K, float radius2, int tiles_per_cloud, int64_t* __restrict__ idxs,
+    int Drt, int K, float radius2, int tiles_per_cloud, const int* __restrict__ grid_flag,
+    const int* __restrict__ qcount, const int* __restrict__ qlist, int64_t* __restrict__ idxs,
     float* __restrict__ dists) {
   const int D = DT > 0 ? DT : Drt;
   const int n = blockIdx.x / tiles_per_cloud;
   const int tile = blockIdx.x - n * tiles_per_cloud;
-  const int i = tile * kBqBlock + threadIdx.x;
-  const bool in_range = i < P1;
+  int i = tile * kBqBlock + threadIdx.x;
+  bool in_range = i < P1;
+  if (grid_flag != nullptr && grid_flag[n]) {  // wave-uniform: this cloud went through the grid
+    if (tile * kBqBlock >= qcount[n]) return;
+    in_range = i < qcount[n];
+    i = in_range ? qlist[(int64_t)n * P1 + i] : 0;
+  }
   const int len1 = (int)lengths1[n];
   int len2 = (int)lengths2[n];
   if (len2 > P2) len2 = P2;
@@ -130,10 +146,26 @@ __global__ __launch_bounds__(kBqBlock) void ball_query_kernel(
 
 using namespace pointops;
 
+// grid path considered (the per-cloud decision is made on the device): D <= 3, K <= 64, clouds large
+// enough for the build passes to pay
+static bool ball_grid_candidate(int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K) {
+  if (const char* e = getenv("POINTOPS_BALL_GRID")) {  // 0 = never, 1 = whenever the shape allows (tests)
+    if (e[0] == '0') return false;
+    if (e[0] == '1') return D <= 3 && K <= 64 && N < 65536 && P2 <= (1 << 20) && N > 0 && P1 > 0 && P2 > 0;
+  }
+  return D <= 3 && K <= 64 && N < 65536 && P2 >= 4096 && P2 <= (1 << 20) &&
+         (double)N * (double)P1 * (double)P2 >= (double)(1LL << 27);
+}
+
+extern "C" size_t pointops_ball_query_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K) {
+  if (!ball_grid_candidate(N, P1, P2, D, K)) return 0;
+  return ball_grid_workspace_bytes(N, P1, P2);
+}
+
 extern "C" int pointops_ball_query(const float* p1, const float* p2, const int64_t* lengths1,
                                    const int64_t* lengths2, int64_t N, int64_t P1, int64_t P2,
                                    int64_t D, int64_t K, float radius, int64_t* idxs, float* dists,
-                                   void* stream_) {
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
   POINTOPS_REQUIRE(N >= 0 && P1 >= 0 && P2 >= 0 && D >= 1 && K >= 0, "ball_query: bad sizes");
   POINTOPS_REQUIRE(P1 < (1LL << 31) && P2 < (1LL << 31) && K < (1LL << 31) && D < (1LL << 16),
                    "ball_query: sizes must fit int32");
@@ -142,10 +174,21 @@ extern "C" int pointops_ball_query(const float* p1, const float* p2, const int64
   const float radius2 = radius * radius;  // fp32 product (ball_query_cpu.cpp:26)
   const int tiles = (int)ceil_div(P1, kBqBlock);
   POINTOPS_REQUIRE(N * tiles < (1LL << 31), "ball_query: grid too large");
+  const int *flag = nullptr, *qcount = nullptr, *qlist = nullptr;
+  const size_t need = pointops_ball_query_workspace_bytes(N, P1, P2, D, K);
+  if (need > 0 && workspace != nullptr && workspace_bytes >= need) {
+    KnnArgs a;
+    a.p1 = p1; a.p2 = p2; a.l1 = lengths1; a.l2 = lengths2;
+    a.P1 = (int)P1; a.P2 = (int)P2; a.D = (int)D; a.K = (int)K; a.N = N;
+    a.tiles = tiles; a.qlist = nullptr; a.qcount = nullptr;
+    a.idxs = idxs; a.dists = dists; a.stream = stream;
+    const int rc = ball_grid_run(a, radius, workspace, &flag, &qcount, &qlist);
+    if (rc != POINTOPS_OK) return rc;
+  }
   const dim3 grid((unsigned)(N * tiles)), block(kBqBlock);
 #define PO_LAUNCH(DT)                                                                            \
   hipLaunchKernelGGL((ball_query_kernel<DT>), grid, block, 0, stream, p1, p2, lengths1, lengths2, \
-                     (int)P1, (int)P2, (int)D, (int)K, radius2, tiles, idxs, dists)
+                     (int)P1, (int)P2, (int)D, (int)K, radius2, tiles, flag, qcount, qlist, idxs, dists)
   switch (D) {
     case 1: PO_LAUNCH(1); break;
     case 2: PO_LAUNCH(2); break;

@@ -35,4 +35,9 @@ int launch_knn_wide(const KnnArgs& a, int norm, void* workspace);
 size_t knn_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K);
 int knn_grid_run(const KnnArgs& a, int norm, void* workspace);
 
+// ball query through the same grid (knn_grid.hip); see ball_query.hip for the operator
+size_t ball_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2);
+int ball_grid_run(const KnnArgs& a, float radius, void* workspace, const int** flag, const int** qcount,
+                  const int** qlist);
+
 }  // namespace pointops

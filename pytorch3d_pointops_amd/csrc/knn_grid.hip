@@ -86,7 +86,10 @@ struct GridWs {
   int* fb3_list;      // N * P1
   unsigned* bbox;     // N * 8: ordered-uint keys of min x,y,z (atomicMin) and max x,y,z (atomicMax)
   int* scan_partial;  // N * 2 * ceil(cell_cap / 4096): per-chunk sums / offsets of the two scans
+  int* grid_flag;     // N          1 = the cloud was searched through its grid (ball query: scan only the list)
   int cell_cap;
+  int ball;           // 0 = KNN (pad rows with idx 0), 1 = ball query (pad with idx -1; clouds without a
+                      //     usable grid are left to the scan kernel instead of the query list)
 };
 
 // ---------------------------------------------------------------------------
@@ -183,7 +186,8 @@ __global__ __launch_bounds__(kBboxBlock) void grid_bbox_kernel(const float* __re
 
 __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     const float* __restrict__ p2, const int64_t* __restrict__ lengths1,
-    const int64_t* __restrict__ lengths2, int P1, int P2, int D, float c_target, int B, GridWs ws) {
+    const int64_t* __restrict__ lengths2, int P1, int P2, int D, float c_target, int B, float h_min,
+    float ball_radius, int ball_K, float ball_factor, GridWs ws) {
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
   int len2 = (int)lengths2[n];
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
           }
         if (k == 0) break;
         h = (float)pow(vol / (double)target_cells, 1.0 / (double)k);
+        if (h < h_min) h = h_min;  // ball query: one cell beyond the query's own must cover the radius
         bool changed = false;
         for (int d = 0; d < 3; ++d)
           if (active[d] && !(e[d] >= h)) {
@@ -234,6 +239,22 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     }
     const bool any_active = active[0] || active[1] || active[2];
     bool ok = finite && (!any_active || (h > 0.0f && h <= FLT_MAX));
+    if (ok && ws.ball) {
+      // Ball query: the index-order scan stops after ~len2 * min(1, K / E) candidates per query
+      // (E = expected points inside the ball), the grid visits ~27 cells >= 6.4 E candidates at a
+      // higher cost each: take the grid only where it wins, factor * E max(E, K) < K len2.
+      int k = 0;
+      double vol = 1.0;
+      for (int d = 0; d < 3; ++d)
+        if (active[d]) {
+          ++k;
+          vol *= (double)e[d];
+        }
+      const double r = (double)ball_radius;
+      const double ball = k == 3 ? 4.18879 * r * r * r : k == 2 ? 3.14159 * r * r : k == 1 ? 2.0 * r : 1.0;
+      const double E = k == 0 ? (double)len2 : fmin((double)len2, (double)len2 * ball / vol);
+      if (!((double)ball_factor * E * fmax(E, (double)ball_K) < (double)ball_K * (double)len2)) ok = false;
+    }
     float inv_h = 1.0f;
     int G[3] = {1, 1, 1};
     if (ok && any_active) {
@@ -273,6 +294,7 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     g.B = B;
     s_g = g;
     ws.cloud[n] = g;
+    ws.grid_flag[n] = g.use_grid;
     ws.fb_count[n] = 0;
     ws.fb2_count[n] = 0;
     ws.fb3_count[n] = 0;
@@ -363,11 +385,12 @@ __global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __rest
       if (i < P && i >= g.len1) {
         int64_t* __restrict__ zi = idxs + ((int64_t)n * P + i) * K;
         float* __restrict__ zd = dists + ((int64_t)n * P + i) * K;
+        const int64_t pad = ws.ball ? -1 : 0;
         for (int k = 0; k < K; ++k) {
-          zi[k] = 0;
+          zi[k] = pad;
           zd[k] = 0.0f;
         }
-      } else if (i < g.len1 && !g.use_grid) {
+      } else if (i < g.len1 && !g.use_grid && !ws.ball) {
         const int pos = atomicAdd(ws.fb2_count + n, 1);
         ws.fb2_list[(int64_t)n * P + pos] = i;
       }
@@ -1388,6 +1411,198 @@ __global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// BALL QUERY through the same grid (ball_query.hip owns the operator; reference semantics
+// ball_query_cpu.cpp:12-54: the first K points in INDEX order with dist2 < radius2).  Cells are at
+// least 1.001 radius wide, so the 3x3x3 cube around the query's cell contains its ball; that is
+// not assumed but CERTIFIED per query with the face bound of the KNN search (lb >= radius2: no
+// unvisited point can pass `dist2 < radius2`), anything else goes to the index-order scan.  One
+// lane per query walks its nine runs exactly like knn_grid_lane_kernel; a hit pushes its INDEX
+// into the lane's LDS queue, queues are merged into a sorted register list of the KC smallest
+// indices by the 32-bit sorting networks (v_min_u32 / v_max_u32 per compare-exchange), and a full
+// list prunes by its largest index.  The list is the output order; distances are recomputed from
+// the chosen points with the scan kernel's expression.
+// ---------------------------------------------------------------------------
+template <int D, int KC>
+__global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
+    const float* __restrict__ p1, const float* __restrict__ p2, const GridCloud* __restrict__ clouds,
+    const int* __restrict__ chunk_prefix, const float* __restrict__ edges, const int* __restrict__ cell_start,
+    const float4* __restrict__ sorted, const int* __restrict__ qlist, int* __restrict__ fb_count,
+    int* __restrict__ fb_list, int cell_cap, int P1, int P2, int K, int N, float radius2,
+    int64_t* __restrict__ idxs, float* __restrict__ dists) {
+  constexpr int kQueueCap = KC < 16 ? KC : 16;
+  constexpr int kSub = 4;
+  constexpr unsigned kNone = 0xffffffffu;
+  __shared__ unsigned s_queue[kQueueCap * kGridWave];
+  __shared__ int2 s_rows[kLaneRows][kGridWave];
+
+  const int lane = threadIdx.x;
+  const int total = chunk_prefix[N];
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    int lo_n = 0, hi_n = N;
+    while (hi_n - lo_n > 1) {
+      const int mid = (lo_n + hi_n) >> 1;
+      if (chunk_prefix[mid] <= item) lo_n = mid;
+      else hi_n = mid;
+    }
+    const int n = lo_n;
+    const GridCloud g = clouds[n];
+    const int c0 = (item - chunk_prefix[n]) * kGridWave;
+    const bool active = c0 + lane < g.len1;
+    const int qi = active ? qlist[(int64_t)n * P1 + c0 + lane] : 0;
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (active) load_point3<D>(p1 + ((int64_t)n * P1 + qi) * D, qx, qy, qz);
+    int cx, cy, cz;
+    point_cells(g, qx, qy, qz, cx, cy, cz);
+    const int X0 = max(cx - 1, 0), X1 = min(cx + 1, g.G[0] - 1);
+    const int Y0 = max(cy - 1, 0), Y1 = min(cy + 1, g.G[1] - 1);
+    const int Z0 = max(cz - 1, 0), Z1 = min(cz + 1, g.G[2] - 1);
+    const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
+    const float4* __restrict__ sp = sorted + (int64_t)n * P2;
+
+    // certification first: a lane whose cube cannot be proven to contain its ball does not walk
+    const float* __restrict__ ed = edges + (int64_t)n * 3 * kEdgeStride;
+    const bool hx0 = X0 > 0, hx1 = X1 < g.G[0] - 1;
+    const bool hy0 = Y0 > 0, hy1 = Y1 < g.G[1] - 1;
+    const bool hz0 = Z0 > 0, hz1 = Z1 < g.G[2] - 1;
+    float lb = __builtin_inff();
+    if (hx0) lb = fminf(lb, face_bound<2>(qx - prev_float(ed[X0])));
+    if (hx1) lb = fminf(lb, face_bound<2>(ed[X1 + 1] - qx));
+    if (hy0) lb = fminf(lb, face_bound<2>(qy - prev_float(ed[kEdgeStride + Y0])));
+    if (hy1) lb = fminf(lb, face_bound<2>(ed[kEdgeStride + Y1 + 1] - qy));
+    if (hz0) lb = fminf(lb, face_bound<2>(qz - prev_float(ed[2 * kEdgeStride + Z0])));
+    if (hz1) lb = fminf(lb, face_bound<2>(ed[2 * kEdgeStride + Z1 + 1] - qz));
+    const bool whole = !(hx0 || hx1 || hy0 || hy1 || hz0 || hz1);
+    const bool ok = whole || lb >= radius2;  // every unvisited point has computed dist2 >= lb
+    const bool walk = active && ok;
+
+#pragma unroll
+    for (int r = 0; r < kLaneRows; ++r) {
+      constexpr int kDz[kLaneRows] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+      constexpr int kDy[kLaneRows] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+      const int z = cz + kDz[r], y = cy + kDy[r];
+      int2 se = make_int2(0, 0);
+      if (walk && z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1]) {
+        const int rowbase = (z * g.G[1] + y) * g.G[0];
+        se.x = cstart[rowbase + X0];
+        se.y = cstart[rowbase + X1 + 1];
+      }
+      s_rows[r][lane] = se;
+    }
+    int r = 0;
+    int cur = s_rows[0][lane].x, end = s_rows[0][lane].y;
+    auto next_record = [&]() -> int {
+      while (cur >= end && r < kLaneRows - 1) {
+        ++r;
+        const int2 se = s_rows[r][lane];
+        cur = se.x;
+        end = se.y;
+      }
+      return cur < end ? cur++ : -1;
+    };
+
+    unsigned top[KC];  // ascending indices, kNone = empty
+#pragma unroll
+    for (int t = 0; t < KC; ++t) top[t] = kNone;
+    unsigned thr = kNone;  // an index must be below the list's largest to matter (stale between flushes)
+    int qn = 0;
+    auto flush = [&]() {
+      unsigned qk[kQueueCap];
+#pragma unroll
+      for (int t = 0; t < kQueueCap; ++t) {
+        const unsigned v = s_queue[t * kGridWave + lane];
+        qk[t] = t < qn ? v : kNone;
+      }
+      bitonic_sort<kQueueCap>(qk);
+#pragma unroll
+      for (int t = 0; t < kQueueCap; ++t) {
+        const unsigned a = top[KC - 1 - t];
+        top[KC - 1 - t] = qk[t] < a ? qk[t] : a;
+      }
+      bitonic_merge<KC>(top);
+      qn = 0;
+      thr = top[KC - 1];
+    };
+    auto fetch = [&](float4 (&c)[kSub]) -> bool {
+      int a[kSub];
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) a[u] = next_record();
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) {
+        const float qnan = __uint_as_float(0x7fc00000u);
+        c[u] = make_float4(qnan, qnan, qnan, 0.f);  // exhausted lanes: NaN distance, never a hit
+        if (a[u] >= 0) c[u] = sp[a[u]];
+      }
+      return a[0] >= 0;
+    };
+    float4 c[kSub];
+    bool more = fetch(c);
+    while (__any(more)) {
+      float4 nxt[kSub];
+      const bool more_next = fetch(nxt);
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) {
+        const float dx = qx - c[u].x;
+        float d = dx * dx;
+        if (D > 1) {
+          const float dy = qy - c[u].y;
+          d = d + dy * dy;
+        }
+        if (D > 2) {
+          const float dz = qz - c[u].z;
+          d = d + dz * dz;
+        }
+        const unsigned j = __float_as_uint(c[u].w);
+        if (d < radius2 && j < thr) {
+          s_queue[qn * kGridWave + lane] = j;
+          ++qn;
+        }
+      }
+      if (__any(qn > kQueueCap - kSub)) flush();
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) c[u] = nxt[u];
+      more = more_next;
+    }
+    flush();
+
+    if (active) {
+      if (ok) {
+        const int64_t row = (int64_t)n * P1 + qi;
+        int64_t* __restrict__ oi = idxs + row * K;
+        float* __restrict__ od = dists + row * K;
+        const float* __restrict__ pts = p2 + (int64_t)n * P2 * D;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+          if (k < K) {
+            const unsigned j = top[k];
+            const bool hit = j != kNone;
+            float d = 0.0f;
+            if (hit) {
+              float bx, by, bz;
+              load_point3<D>(pts + (int64_t)j * D, bx, by, bz);
+              const float dx = qx - bx;
+              d = dx * dx;
+              if (D > 1) {
+                const float dy = qy - by;
+                d = d + dy * dy;
+              }
+              if (D > 2) {
+                const float dz = qz - bz;
+                d = d + dz * dz;
+              }
+            }
+            oi[k] = hit ? (int64_t)j : -1;
+            od[k] = d;
+          }
+        }
+      } else {
+        const int pos = atomicAdd(fb_count + n, 1);
+        fb_list[(int64_t)n * P1 + pos] = qi;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1415,10 +1630,7 @@ static int grid_cell_cap(int64_t P2, float c_target) {
   return (int)(2 * cells + 64);
 }
 
-static size_t carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, int K) {
-  float c;
-  int B;
-  grid_tuning(K, &c, &B);
+static size_t carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, float c) {
   const int cap = grid_cell_cap(P2, c);
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -1445,12 +1657,21 @@ static size_t carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, i
   w.fb3_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.bbox = (unsigned*)take(sizeof(unsigned) * (size_t)N * 8);
   w.scan_partial = (int*)take(sizeof(int) * (size_t)N * 2 * (size_t)((cap + kScanChunk - 1) / kScanChunk));
+  w.grid_flag = (int*)take(sizeof(int) * (size_t)N);
+  w.ball = 0;
   if (ws) *ws = w;
   return off;
 }
 
+static float knn_cell_target(int K) {
+  float c;
+  int B;
+  grid_tuning(K, &c, &B);
+  return c;
+}
+
 size_t knn_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K) {
-  return carve(nullptr, nullptr, N, P1, P2, (int)K);
+  return carve(nullptr, nullptr, N, P1, P2, knn_cell_target((int)K));
 }
 
 template <int D, int KC, int NORM>
@@ -1513,7 +1734,7 @@ static void dispatch_grid_k(const KnnArgs& a, const GridWs& ws, int wgs) {
 }
 
 template <int D>
-static void run_d(const KnnArgs& a, int norm, const GridWs& ws, int wgs) {
+static void build_d(const KnnArgs& a, const GridWs& ws) {
   const dim3 g2((unsigned)ceil_div(a.P2, kBinTile), (unsigned)a.N), g1((unsigned)ceil_div(a.P1, kBinTile), (unsigned)a.N);
   hipLaunchKernelGGL((grid_bin_kernel<D, false, false>), g2, dim3(kBinBlock), 0, a.stream, a.p2, a.P2, a.K, ws, a.idxs,
                      a.dists);
@@ -1529,6 +1750,11 @@ static void run_d(const KnnArgs& a, int norm, const GridWs& ws, int wgs) {
                      a.dists);
   hipLaunchKernelGGL((grid_bin_kernel<D, true, true>), g1, dim3(kBinBlock), 0, a.stream, a.p1, a.P1, a.K, ws, a.idxs,
                      a.dists);
+}
+
+template <int D>
+static void run_d(const KnnArgs& a, int norm, const GridWs& ws, int wgs) {
+  build_d<D>(a, ws);
   if (norm == 1) dispatch_grid_k<D, 1>(a, ws, wgs);
   else dispatch_grid_k<D, 2>(a, ws, wgs);
 }
@@ -1537,10 +1763,10 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
   POINTOPS_REQUIRE(a.N < 65536, "knn_points_idx(grid): batch must be < 65536");
   POINTOPS_REQUIRE(a.P2 <= (1 << 20), "knn_points_idx(grid): P2 must be <= 2^20");
   GridWs ws;
-  carve(&ws, (char*)workspace, a.N, a.P1, a.P2, a.K);
   float c;
   int B;
   grid_tuning(a.K, &c, &B);
+  carve(&ws, (char*)workspace, a.N, a.P1, a.P2, c);
   const bool lane_mode = grid_lane_mode();
   if (lane_mode) B = 1;  // queries sorted by cell
   // histogram buffers (cell_count and blk_count are adjacent) start at zero
@@ -1551,7 +1777,7 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
   hipLaunchKernelGGL(grid_bbox_kernel, dim3((unsigned)ceil_div(a.P2, kBboxBlock * kBboxPerThread), (unsigned)a.N),
                      dim3(kBboxBlock), 0, a.stream, a.p2, a.l2, a.P2, a.D, ws.bbox);
   hipLaunchKernelGGL(grid_setup_kernel, dim3((unsigned)a.N), dim3(kSetupBlock), 0, a.stream, a.p2, a.l1, a.l2,
-                     a.P1, a.P2, a.D, c, B, ws);
+                     a.P1, a.P2, a.D, c, B, 0.0f, 0.0f, 0, 0.0f, ws);
   hipLaunchKernelGGL(grid_prefix_kernel, dim3(1), dim3(64), 0, a.stream, ws, (int)a.N, lane_mode ? 1 : 0);
   const int wgs = 256 * 32;  // one wave64 per workgroup, up to 32 waves per CU resident
   switch (a.D) {
@@ -1569,6 +1795,64 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
   return check_launch("knn_points_idx(grid fallback)");
 }
 
+// ---------------------------------------------------------------------------
+// ball query host side
+// ---------------------------------------------------------------------------
+constexpr float kBallCellTarget = 2.0f;  // density floor of the cell size; the radius usually decides
+
+size_t ball_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2) {
+  return carve(nullptr, nullptr, N, P1, P2, kBallCellTarget);
+}
+
+template <int D>
+static void ball_run_d(const KnnArgs& a, float radius2, const GridWs& ws, int wgs) {
+  build_d<D>(a, ws);
+#define PO_BALL(KC)                                                                                              \
+  hipLaunchKernelGGL((ball_grid_lane_kernel<D, KC>), dim3((unsigned)wgs), dim3(kGridWave), 0, a.stream, a.p1, a.p2, \
+                     (const GridCloud*)ws.cloud, (const int*)ws.block_prefix, (const float*)ws.edges,            \
+                     (const int*)ws.cell_start, (const float4*)ws.sorted, (const int*)ws.qlist, ws.fb2_count,    \
+                     ws.fb2_list, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, radius2, a.idxs, a.dists)
+  if (a.K <= 8) PO_BALL(8);
+  else if (a.K <= 16) PO_BALL(16);
+  else if (a.K <= 32) PO_BALL(32);
+  else PO_BALL(64);
+#undef PO_BALL
+}
+
+// Builds the grids and answers every query it can certify.  On return (stream order) flag[n] = 1 for
+// the clouds that were searched through their grid -- for those only the qcount[n] queries of
+// qlist[n * P1 ..] are left -- and 0 for the clouds the index-order scan has to do in full.
+int ball_grid_run(const KnnArgs& a, float radius, void* workspace, const int** flag, const int** qcount,
+                  const int** qlist) {
+  POINTOPS_REQUIRE(a.N < 65536 && a.P2 <= (1 << 20) && a.K <= 64 && a.D <= 3, "ball_query(grid): unsupported shape");
+  GridWs ws;
+  carve(&ws, (char*)workspace, a.N, a.P1, a.P2, kBallCellTarget);
+  ws.ball = 1;
+  const size_t zero_bytes = (size_t)((char*)ws.cell_start - (char*)ws.cell_count);
+  if (hipMemsetAsync(ws.cell_count, 0, zero_bytes, a.stream) != hipSuccess) return check_launch("ball grid memset");
+  hipLaunchKernelGGL(grid_bbox_init_kernel, dim3((unsigned)ceil_div(a.N * 8, 256)), dim3(256), 0, a.stream, ws.bbox,
+                     (int)a.N);
+  hipLaunchKernelGGL(grid_bbox_kernel, dim3((unsigned)ceil_div(a.P2, kBboxBlock * kBboxPerThread), (unsigned)a.N),
+                     dim3(kBboxBlock), 0, a.stream, a.p2, a.l2, a.P2, a.D, ws.bbox);
+  const float h_min = fabsf(radius) * 1.001f;
+  float factor = 5.0f;  // measured crossover (grid wins where K len2 / (E max(E, K)) > ~4-7), profiles/r01_ball_crossover.txt
+  if (const char* e = getenv("POINTOPS_BALL_FACTOR")) factor = (float)atof(e);  // tuning experiments only
+  hipLaunchKernelGGL(grid_setup_kernel, dim3((unsigned)a.N), dim3(kSetupBlock), 0, a.stream, a.p2, a.l1, a.l2,
+                     a.P1, a.P2, a.D, kBallCellTarget, 1, h_min, fabsf(radius), a.K, factor, ws);
+  hipLaunchKernelGGL(grid_prefix_kernel, dim3(1), dim3(64), 0, a.stream, ws, (int)a.N, 1);
+  const int wgs = 256 * 32;
+  const float radius2 = radius * radius;  // fp32 product (ball_query_cpu.cpp:26)
+  switch (a.D) {
+    case 1: ball_run_d<1>(a, radius2, ws, wgs); break;
+    case 2: ball_run_d<2>(a, radius2, ws, wgs); break;
+    default: ball_run_d<3>(a, radius2, ws, wgs); break;
+  }
+  *flag = ws.grid_flag;
+  *qcount = ws.fb2_count;
+  *qlist = ws.fb2_list;
+  return check_launch("ball_query(grid)");
+}
+
 }  // namespace pointops
 
 extern "C" int pointops_knn_grid_fallback_counts(const void* workspace, int64_t N, int64_t P1, int64_t P2,
@@ -1576,7 +1860,7 @@ extern "C" int pointops_knn_grid_fallback_counts(const void* workspace, int64_t 
   using namespace pointops;
   POINTOPS_REQUIRE(workspace != nullptr && counts != nullptr && N > 0, "knn_grid_fallback_counts: bad arguments");
   GridWs ws;
-  carve(&ws, (char*)workspace, N, P1, P2, (int)K);
+  carve(&ws, (char*)workspace, N, P1, P2, knn_cell_target((int)K));
   if (hipMemcpyAsync(counts + N, ws.fb2_count, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice,
                      (hipStream_t)stream) != hipSuccess)
     return check_launch("knn_grid_fallback_counts");

@@ -66,4 +66,28 @@ __device__ __forceinline__ void bitonic_merge(unsigned long long (&a)[N]) {  // 
   }
 }
 
+
+// 32-bit keys (ball query: point indices): a compare-exchange is v_min_u32 + v_max_u32
+__device__ __forceinline__ void key_ce(unsigned& a, unsigned& b, bool) {
+  const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+  a = lo;
+  b = hi;
+}
+template <int N>
+__device__ __forceinline__ void bitonic_sort(unsigned (&a)[N]) {  // ascending
+#pragma unroll
+  for (int i = 0; i < SortNet<N>::kSize; ++i) key_ce(a[SortNet<N>::kA[i]], a[SortNet<N>::kB[i]], true);
+}
+template <int N>
+__device__ __forceinline__ void bitonic_merge(unsigned (&a)[N]) {  // bitonic -> ascending
+#pragma unroll
+  for (int j = N >> 1; j > 0; j >>= 1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int l = i ^ j;
+      if (l > i) key_ce(a[i], a[l], true);
+    }
+  }
+}
+
 }  // namespace pointops

@@ -344,6 +344,44 @@ def test_ball_query_larger_clouds(dev, oracle, radius, K):
     assert np.array_equal(bits(d.cpu().numpy()), bits(od))
 
 
+@pytest.mark.parametrize("name", sorted(cases.ball_query_cases()))
+def test_ball_query_grid_matches_golden(dev, monkeypatch, name):
+    """The cell-grid path (forced on: these clouds are far below its automatic size threshold) gives
+    the reference's results bit for bit, including the strict-< lattice boundary and D = 2."""
+    from pytorch3d_pointops_amd import _C
+
+    g = load_golden("ball_query")
+    c = cases.ball_query_cases()[name]
+    monkeypatch.setenv("POINTOPS_BALL_GRID", "1")
+    idx, d = _C.ball_query(G(c["p1"], dev), G(c["p2"], dev), G(c["l1"], dev), G(c["l2"], dev), c["K"], c["radius"])
+    assert np.array_equal(idx.cpu().numpy(), g[name + "/idx"].astype(np.int64))
+    assert np.array_equal(bits(d.cpu().numpy()), bits(g[name + "/dists"]))
+
+
+@pytest.mark.parametrize("radius,K,D", [(0.05, 16, 3), (0.02, 32, 3), (0.3, 8, 3), (0.12, 64, 3), (1e-4, 4, 3),
+                                        (0.01, 8, 2), (0.001, 5, 1), (0.05, 100, 3), (-0.05, 16, 3)])
+def test_ball_query_grid_vs_oracle(dev, oracle, monkeypatch, radius, K, D):
+    """Grid path on larger ragged clouds (sparse balls -> grid, dense balls -> the device picks the
+    scan, K = 100 -> no grid, clustered and offset data, an empty cloud), against the oracle and
+    against the scan-only path."""
+    from pytorch3d_pointops_amd import _C
+
+    p1 = cases.cloud(1801, (3, 3000, D))
+    p2 = cases.cloud(1802, (3, 20000, D))
+    p2[1] = (p2[1] ** np.float32(3.0)).astype(np.float32) + np.float32(10.0)  # clustered, far from the origin
+    p1[1] = (p1[1] ** np.float32(3.0)).astype(np.float32) + np.float32(10.0)
+    l1 = np.array([3000, 1234, 77])
+    l2 = np.array([20000, 6000, 0])
+    monkeypatch.setenv("POINTOPS_BALL_GRID", "1")
+    idx, d = _C.ball_query(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), K, radius)
+    oi, od = oracle.ball_query(p1, p2, l1, l2, K, radius)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(bits(d.cpu().numpy()), bits(od))
+    monkeypatch.setenv("POINTOPS_BALL_GRID", "0")
+    idx0, d0 = _C.ball_query(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), K, radius)
+    assert torch.equal(idx, idx0) and torch.equal(d.view(torch.int32), d0.view(torch.int32))
+
+
 # ------------------------------------------------------------------ FPS
 @pytest.mark.parametrize("name", sorted(cases.fps_cases()))
 def test_sample_farthest_points(dev, oracle, name):

@@ -52,6 +52,12 @@ def main():
         ms, mn = timeit(lambda: _C.ball_query(pts, pts, L, L, 32, 0.2))
         outb = Bc * Pc * 32 * 12 + Bc * Pc * 12
         emit("ball_query B=16 N=131072 r=0.2 K=32", ms, mn, algo_GBs=outb / ms / 1e6)
+        for (rr, kk, b) in ((0.05, 32, 16), (0.02, 32, 16), (0.01, 16, 16), (0.02, 32, 2)):
+            for g in ("1", "0"):
+                os.environ["POINTOPS_BALL_GRID"] = g
+                ms2, mn2 = timeit(lambda: _C.ball_query(pts[:b], pts[:b], L[:b], L[:b], kk, rr), warmup=1, iters=3)
+                emit(f"ball_query B={b} N=131072 r={rr} K={kk} [grid={g}]", ms2, mn2)
+        del os.environ["POINTOPS_BALL_GRID"]
         ms, mn = timeit(lambda: ball_query(pts, pts, L, L, K=32, radius=0.2, return_nn=True))
         emit("ball_query(+return_nn) B=16 N=131072", ms, mn, algo_GBs=(outb + Bc * Pc * 32 * 12) / ms / 1e6)
     if "fps" in ops:
