@@ -31,6 +31,46 @@ __global__ __launch_bounds__(kGaBlock) void gather_kernel(
   out[e] = ok ? x[(n * M + j) * U + u] : 0.0f;
 }
 
+// U <= 4: one lane per (n,l,k) ROW -- the index is read once, the U values leave as one 4/8/12/16
+// byte store per lane (contiguous across the wave), and all index arithmetic is 32-bit within a
+// cloud (grid.y = cloud); the per-element kernel above spends most of its time in 64-bit divisions.
+template <int U>
+struct alignas(4) GaRow { float v[U]; };
+
+template <int U>
+__global__ __launch_bounds__(kGaBlock) void gather_rows_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ idx, const int64_t* __restrict__ lengths, int M,
+    int LK, int K, float* __restrict__ out) {
+  const int n = blockIdx.y;
+  const int e = blockIdx.x * kGaBlock + threadIdx.x;
+  if (e >= LK) return;
+  const int k = e % K;
+  const int64_t r = (int64_t)n * LK + e;
+  const int64_t j = idx[r];
+  bool ok = j >= 0 && j < M;
+  if (lengths != nullptr) ok = ok && (int64_t)k < lengths[n];
+  GaRow<U> v;
+#pragma unroll
+  for (int u = 0; u < U; ++u) v.v[u] = 0.0f;
+  if (ok) v = *reinterpret_cast<const GaRow<U>*>(x + ((int64_t)n * M + j) * U);
+  *reinterpret_cast<GaRow<U>*>(out + r * U) = v;
+}
+
+// any U, one lane per element, 32-bit arithmetic within a cloud (LK * U < 2^31)
+__global__ __launch_bounds__(kGaBlock) void gather_elems32_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ idx, const int64_t* __restrict__ lengths, int M, int U,
+    int LK, int K, float* __restrict__ out) {
+  const int n = blockIdx.y;
+  const unsigned e = blockIdx.x * (unsigned)kGaBlock + threadIdx.x;
+  if (e >= (unsigned)LK * (unsigned)U) return;
+  const unsigned r = e / (unsigned)U, u = e - r * (unsigned)U;
+  const int k = (int)(r % (unsigned)K);
+  const int64_t j = idx[(int64_t)n * LK + r];
+  bool ok = j >= 0 && j < M;
+  if (lengths != nullptr) ok = ok && (int64_t)k < lengths[n];
+  out[((int64_t)n * LK + r) * U + u] = ok ? x[((int64_t)n * M + j) * U + u] : 0.0f;
+}
+
 __global__ __launch_bounds__(kGaBlock) void gather_backward_kernel(
     const float* __restrict__ grad_out, const int64_t* __restrict__ idx,
     const int64_t* __restrict__ lengths, int64_t total, int64_t M, int U, int64_t LK, int K,
@@ -84,6 +124,25 @@ extern "C" int pointops_gather_neighbors(const float* x, const int64_t* idx, con
                    "gather_neighbors: bad sizes");
   const int64_t total = N * L * K * U;
   if (total == 0) return POINTOPS_OK;
+  const int64_t LK = L * K;
+  if (N < 65536 && M < (1LL << 31) && LK * U < (1LL << 31)) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (U <= 4) {
+      const dim3 grid((unsigned)ceil_div(LK, kGaBlock), (unsigned)N), block(kGaBlock);
+#define PO_ROWS(UU) \
+  hipLaunchKernelGGL(gather_rows_kernel<UU>, grid, block, 0, stream, x, idx, lengths, (int)M, (int)LK, (int)K, out)
+      if (U == 1) PO_ROWS(1);
+      else if (U == 2) PO_ROWS(2);
+      else if (U == 3) PO_ROWS(3);
+      else PO_ROWS(4);
+#undef PO_ROWS
+    } else {
+      const dim3 grid((unsigned)ceil_div(LK * U, kGaBlock), (unsigned)N), block(kGaBlock);
+      hipLaunchKernelGGL(gather_elems32_kernel, grid, block, 0, stream, x, idx, lengths, (int)M, (int)U, (int)LK,
+                         (int)K, out);
+    }
+    return check_launch("gather_neighbors");
+  }
   const int64_t blocks = ceil_div(total, kGaBlock);
   POINTOPS_REQUIRE(blocks < (1LL << 31), "gather_neighbors: grid too large");
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)blocks), dim3(kGaBlock), 0, (hipStream_t)stream_, x,

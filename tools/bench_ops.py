@@ -104,6 +104,10 @@ def main():
         ms, mn = timeit(lambda: knn_gather(xg, ig))
         emit("knn_gather B=32 N=65536 K=16 U=3", ms, mn, algo_GBs=(Bg * Pg * Kg * (8 + 12) + Bg * Pg * 12) / ms / 1e6)
     if "gather" in ops:
+        xw = torch.from_numpy(synth.uniform_f32(64, (8, 16384, 64))).to(dev)
+        iw = torch.from_numpy(synth.randint(65, 0, 16383, (8, 16384, 16))).to(dev)
+        ms, mn = timeit(lambda: knn_gather(xw, iw))
+        emit("knn_gather B=8 N=16384 K=16 U=64", ms, mn, algo_GBs=(8 * 16384 * 16 * (8 + 256) + 8 * 16384 * 256) / ms / 1e6)
         gg = torch.from_numpy(synth.uniform_f32(63, (Bg, Pg, Kg, 3))).to(dev)
         for mode in ("tiled", "atomic"):
             os.environ["POINTOPS_GATHER_BWD_MODE"] = mode
