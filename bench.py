@@ -186,8 +186,8 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": traffic_src,
-            "kernel": "knn_points_idx = grid build (bbox, histogram, scan, counting sort) + knn_grid_kernel "
-                      "(dominant, ~70 % of the step) + exact fallbacks; `achieved` prices the WHOLE op, "
+            "kernel": "knn_points_idx = grid build (bbox, histogram, scan, counting sort) + knn_grid_lane_kernel "
+                      "(dominant, ~75 % of the step) + exact fallbacks; `achieved` prices the WHOLE op, "
                       "HIP-event timed on the launch stream",
             "algorithmic_bytes_per_launch": algo_bytes,
             "avg_launch_ms": avg_kern_s * 1e3,

@@ -289,8 +289,8 @@ static int choose_version(int version, int64_t N, int64_t P1, int64_t P2, int64_
   // crossover in total pairs grows as K shrinks, because short lists make the scan cheap per pair
   // (measured v2 against v3, N = 1..32 clouds of 4096..32768 points, profiles/r01_knn_crossover.txt).
   const double pairs = (double)N * (double)P1 * (double)P2;
-  const double cross = K <= 2 ? 1.5 * (double)(1LL << 29) : K <= 4 ? (double)(1LL << 29) : K <= 8 ? (double)(1LL << 28)
-                       : K <= 16 ? (double)(1LL << 27) : (double)(1LL << 24);
+  const double cross = K <= 2 ? 1.5 * (double)(1LL << 29) : K <= 4 ? (double)(1LL << 28) : K <= 8 ? (double)(1LL << 27)
+                       : (double)(1LL << 24);
   if (grid_ok && P2 >= 4096 && pairs >= cross) return 3;
   if (pointops_knn_check_version(2, D, K)) return 2;
   return 0;

@@ -1697,15 +1697,18 @@ static void launch_grid_lane(const KnnArgs& a, const GridWs& ws, int wgs) {
                      ws.fb_list, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
 }
 
-static bool grid_quad_mode() {
-  // POINTOPS_GRID_QUAD=0 sends uncertified queries straight to the expanding wave search (A/B measurements)
-  const char* e = getenv("POINTOPS_GRID_QUAD");
-  return !(e && e[0] == '0');
+static bool grid_quad_mode(int P1) {
+  // The quad pass has a ~90 us floor (one wave walking ~200 candidates per lane), which only pays
+  // when a cloud sends it hundreds of queries: measured 1.16 vs 1.23 ms at 32 x 65536 queries, but
+  // 0.33 vs 0.24 ms at 32 x 4096, where the expanding wave search takes the uncertified queries
+  // directly.  POINTOPS_GRID_QUAD=0/1 forces the choice (A/B measurements).
+  if (const char* e = getenv("POINTOPS_GRID_QUAD")) return e[0] != '0';
+  return P1 >= 32768;
 }
 
 template <int D, int KC, int NORM>
 static void launch_grid_wave(const KnnArgs& a, const GridWs& ws) {
-  const bool quad = grid_quad_mode();
+  const bool quad = grid_quad_mode(a.P1);
   if (quad) {
     int64_t wx = a.P1 / (32 * kQuadQueries);  // a few % of a cloud arrive here
     wx = wx < 8 ? 8 : wx > 4096 ? 4096 : wx;
