@@ -56,6 +56,7 @@ constexpr int kEdgeStride = kGMax + 2;
 constexpr int kSetupBlock = 256;
 constexpr int kScanBlock = 1024;
 constexpr int kGridWave = 64;
+constexpr int kBinLdsBinsSetup = 40000;  // = kBinLdsBins of the binning pass (defined with it below)
 
 struct GridCloud {
   float lo[3];
@@ -274,8 +275,13 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
           }
           cells *= G[d];
         }
-        if (cells <= (long long)ws.cell_cap) break;
-        h *= 1.2599211f;  // halve the cell count and retry
+        // A histogram that fits the binning pass's LDS table is ~3x cheaper to build than one that
+        // needs a global atomic per point: when the cell count is within 2x of the table, grow h a
+        // little (cells ~ h^-3) until it fits.
+        if (cells <= (long long)ws.cell_cap &&
+            !(cells > (long long)kBinLdsBinsSetup && cells <= 2LL * kBinLdsBinsSetup))
+          break;
+        h *= cells > (long long)ws.cell_cap ? 1.2599211f : 1.04f;  // halve the cell count / nudge
       }
       if ((long long)G[0] * G[1] * G[2] > (long long)ws.cell_cap) ok = false;
     }
@@ -359,7 +365,8 @@ __device__ __forceinline__ void point_cells(const GridCloud& g, float x, float y
 constexpr int kBinBlock = 1024;
 constexpr int kBinPerThread = 16;
 constexpr int kBinTile = kBinBlock * kBinPerThread;
-constexpr int kBinLdsBins = 16384;  // 64 KiB of LDS
+static_assert(kBinLdsBinsSetup == 40000, "keep in sync");
+constexpr int kBinLdsBins = 40000;  // 156 KiB of LDS: the whole CU's LDS, one workgroup per CU
 
 template <int D, bool SCATTER, bool IS_QUERY>
 __global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __restrict__ pts, int P, int K, GridWs ws,
@@ -1607,7 +1614,14 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
 // ---------------------------------------------------------------------------
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static int grid_kc(int K) { return K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : K <= 24 ? 24 : 32; }
+static bool grid_lane_mode();
+
+// list capacity of the search kernels.  24 only exists for the block form: in the lane-private form a
+// 24-slot list has no sorting network (direct inserts: 2.9 ms at cfg2 size) and loses to the 32-slot
+// queue/network variant (2.4 ms).
+static int grid_kc(int K) {
+  return K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : (K <= 24 && !grid_lane_mode()) ? 24 : 32;
+}
 
 static void grid_tuning(int K, float* c_target, int* B) {
   // the search keeps the KC >= K best and certifies the KC-th, so size the cells for KC
@@ -1732,7 +1746,7 @@ static void dispatch_grid_k(const KnnArgs& a, const GridWs& ws, int wgs) {
   else if (K <= 4) { if (grid_lane_mode()) launch_grid_lane<D, 4, NORM>(a, ws, wgs); else launch_grid_search<D, 4, NORM>(a, ws, wgs); launch_grid_wave<D, 4, NORM>(a, ws); }
   else if (K <= 8) { if (grid_lane_mode()) launch_grid_lane<D, 8, NORM>(a, ws, wgs); else launch_grid_search<D, 8, NORM>(a, ws, wgs); launch_grid_wave<D, 8, NORM>(a, ws); }
   else if (K <= 16) { if (grid_lane_mode()) launch_grid_lane<D, 16, NORM>(a, ws, wgs); else launch_grid_search<D, 16, NORM>(a, ws, wgs); launch_grid_wave<D, 16, NORM>(a, ws); }
-  else if (K <= 24) { if (grid_lane_mode()) launch_grid_lane<D, 24, NORM>(a, ws, wgs); else launch_grid_search<D, 24, NORM>(a, ws, wgs); launch_grid_wave<D, 24, NORM>(a, ws); }
+  else if (K <= 24 && !grid_lane_mode()) { launch_grid_search<D, 24, NORM>(a, ws, wgs); launch_grid_wave<D, 24, NORM>(a, ws); }
   else { if (grid_lane_mode()) launch_grid_lane<D, 32, NORM>(a, ws, wgs); else launch_grid_search<D, 32, NORM>(a, ws, wgs); launch_grid_wave<D, 32, NORM>(a, ws); }
 }
 
