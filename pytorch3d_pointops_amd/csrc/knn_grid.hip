@@ -87,6 +87,8 @@ struct GridWs {
   int* fb3_list;      // N * P1
   unsigned* bbox;     // N * 8: ordered-uint keys of min x,y,z (atomicMin) and max x,y,z (atomicMax)
   int* scan_partial;  // N * 2 * ceil(cell_cap / 4096): per-chunk sums / offsets of the two scans
+  int* rank1;         // N * P1     rank of a query / point inside its bin (many-bin clouds only)
+  int* rank2;         // N * P2
   int* grid_flag;     // N          1 = the cloud was searched through its grid (ball query: scan only the list)
   int cell_cap;
   int ball;           // 0 = KNN (pad rows with idx 0), 1 = ball query (pad with idx -1; clouds without a
@@ -380,6 +382,7 @@ __global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __rest
   const int64_t cbase = (int64_t)n * ws.cell_cap;
   int* __restrict__ gcount = (IS_QUERY ? ws.blk_count : ws.cell_count) + cbase;
   const int* __restrict__ gstart = (IS_QUERY ? ws.blk_start : ws.cell_start) + (int64_t)n * (ws.cell_cap + 1);
+  int* __restrict__ grank = (IS_QUERY ? ws.rank1 : ws.rank2) + (int64_t)n * P;
   const int i0 = blockIdx.x * kBinTile + tid;
   if (blockIdx.x * kBinTile >= P) return;
 
@@ -432,9 +435,11 @@ __global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __rest
       if (use_lds) {
         rank[r] = atomicAdd(&s_hist[bin[r]], 1);  // LDS atomic: rank inside (tile, bin)
       } else if (!SCATTER) {
-        atomicAdd(gcount + bin[r], 1);
+        // too many bins for the LDS table: one device atomic per point, whose return value is the
+        // point's rank in its bin -- remembered, so that the scatter pass needs no second atomic
+        grank[i] = atomicAdd(gcount + bin[r], 1);
       } else {
-        rank[r] = gstart[bin[r]] + atomicAdd(gcount + bin[r], 1);  // final position
+        rank[r] = gstart[bin[r]] + grank[i];  // final position
       }
     }
   }
@@ -1672,6 +1677,8 @@ static size_t carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, f
   w.bbox = (unsigned*)take(sizeof(unsigned) * (size_t)N * 8);
   w.scan_partial = (int*)take(sizeof(int) * (size_t)N * 2 * (size_t)((cap + kScanChunk - 1) / kScanChunk));
   w.grid_flag = (int*)take(sizeof(int) * (size_t)N);
+  w.rank1 = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
+  w.rank2 = (int*)take(sizeof(int) * (size_t)N * (size_t)P2);
   w.ball = 0;
   if (ws) *ws = w;
   return off;
