@@ -132,7 +132,7 @@ __device__ float edge_bisect(int c, float lo, float hi, float inv_h, int G) {
 // pass 0: bounding boxes, all CUs.  fp32 min/max through order-preserving uint keys and
 // atomicMin / atomicMax (keys pre-set by grid_bbox_init_kernel).
 constexpr int kBboxBlock = 256;
-constexpr int kBboxPerThread = 16;
+constexpr int kBboxPerThread = 32;
 
 __global__ void grid_bbox_init_kernel(unsigned* __restrict__ bbox, int N) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -176,14 +176,27 @@ __global__ __launch_bounds__(kBboxBlock) void grid_bbox_kernel(const float* __re
       mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, kWave));
     }
   }
-  if ((threadIdx.x & (kWave - 1)) == 0) {
+  // one atomic per workgroup and bound (the 6 keys of a cloud are hot addresses)
+  __shared__ float s_mn[kBboxBlock / kWave][3], s_mx[kBboxBlock / kWave][3];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == 0) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      if (d < D) {
-        atomicMin(bbox + n * 8 + d, fkey(mn[d]));
-        atomicMax(bbox + n * 8 + 3 + d, fkey(mx[d]));
-      }
+      s_mn[wave][d] = mn[d];
+      s_mx[wave][d] = mx[d];
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 && (int)threadIdx.x < D) {
+    const int d = threadIdx.x;
+    float a = s_mn[0][d], b = s_mx[0][d];
+#pragma unroll
+    for (int w = 1; w < kBboxBlock / kWave; ++w) {
+      a = fminf(a, s_mn[w][d]);
+      b = fmaxf(b, s_mx[w][d]);
+    }
+    atomicMin(bbox + n * 8 + d, fkey(a));
+    atomicMax(bbox + n * 8 + 3 + d, fkey(b));
   }
 }
 
@@ -324,17 +337,25 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
 // Chunk k of block b lives in slot  (blk_start[b] >> 6) + b + k : the slot ranges of
 // consecutive blocks never overlap (floor((s+q)/64) - floor(s/64) + 1 >= ceil(q/64)) and a
 // cloud needs at most len1/64 + nblock + 1 slots; empty slots are skipped.
-__global__ void grid_prefix_kernel(GridWs ws, int N, int lane_mode) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    int acc = 0;
-    ws.block_prefix[0] = 0;
-    for (int n = 0; n < N; ++n) {
+__global__ void grid_prefix_kernel(GridWs ws, int N, int lane_mode) {  // one wave
+  const int lane = threadIdx.x;
+  int acc = 0;
+  if (lane == 0) ws.block_prefix[0] = 0;
+  for (int n0 = 0; n0 < N; n0 += kWave) {
+    const int n = n0 + lane;
+    int items = 0;
+    if (n < N) {
       const GridCloud g = ws.cloud[n];
-      int items = 0;
       if (g.use_grid) items = lane_mode ? (g.len1 + kGridWave - 1) / kGridWave : (g.len1 / kGridWave + g.nblock + 1);
-      acc += items;
-      ws.block_prefix[n + 1] = acc;
     }
+    int inc = items;  // inclusive wave scan
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int v = __shfl_up(inc, off, kWave);
+      if (lane >= off) inc += v;
+    }
+    if (n < N) ws.block_prefix[n + 1] = acc + inc;
+    acc += __shfl(inc, kWave - 1, kWave);
   }
 }
 
