@@ -56,6 +56,7 @@ constexpr int kEdgeStride = kGMax + 2;
 constexpr int kSetupBlock = 256;
 constexpr int kScanBlock = 1024;
 constexpr int kGridWave = 64;
+constexpr int kNumXcd = 8;  // MI355X: 8 XCDs x 32 CUs, private 4 MB L2 each
 constexpr int kBinLdsBinsSetup = 40000;  // = kBinLdsBins of the binning pass (defined with it below)
 
 struct GridCloud {
@@ -869,7 +870,14 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
 
   const int lane = threadIdx.x;
   const int total = chunk_prefix[N];
-  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+  // XCD-aware item order: workgroup b runs on XCD b % 8 (round-robin dispatch), and the chunks are
+  // sorted by (cloud, cell).  Each XCD walks its own contiguous eighth of the chunk list, so the
+  // ~1000 chunks it has in flight belong to one or two clouds whose sorted records (1 MB at 65536
+  // points) stay in that XCD's 4 MB L2, instead of every XCD touching every cloud in flight.
+  const int xcd = blockIdx.x % kNumXcd, per_xcd = (total + kNumXcd - 1) / kNumXcd;
+  for (int j = blockIdx.x / kNumXcd; j < per_xcd; j += gridDim.x / kNumXcd) {
+    const int item = xcd * per_xcd + j;
+    if (item >= total) break;
     int lo_n = 0, hi_n = N;
     while (hi_n - lo_n > 1) {
       const int mid = (lo_n + hi_n) >> 1;
@@ -1470,7 +1478,14 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
 
   const int lane = threadIdx.x;
   const int total = chunk_prefix[N];
-  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+  // XCD-aware item order: workgroup b runs on XCD b % 8 (round-robin dispatch), and the chunks are
+  // sorted by (cloud, cell).  Each XCD walks its own contiguous eighth of the chunk list, so the
+  // ~1000 chunks it has in flight belong to one or two clouds whose sorted records (1 MB at 65536
+  // points) stay in that XCD's 4 MB L2, instead of every XCD touching every cloud in flight.
+  const int xcd = blockIdx.x % kNumXcd, per_xcd = (total + kNumXcd - 1) / kNumXcd;
+  for (int j = blockIdx.x / kNumXcd; j < per_xcd; j += gridDim.x / kNumXcd) {
+    const int item = xcd * per_xcd + j;
+    if (item >= total) break;
     int lo_n = 0, hi_n = N;
     while (hi_n - lo_n > 1) {
       const int mid = (lo_n + hi_n) >> 1;
