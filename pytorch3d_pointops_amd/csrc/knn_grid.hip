@@ -855,6 +855,17 @@ __device__ __forceinline__ unsigned seed_threshold(float lb, bool whole) {
 // and the certification bound are the same, evaluated on the lane's own cube.
 // ---------------------------------------------------------------------------
 constexpr int kLaneRows = 9;
+// Two measured-and-dropped forms of the lane search stay selectable at compile time (tools/build_variant.py):
+//  PINGPONG = 1  two candidate buffers with the loop body written twice (saves the 16 v_mov_b64 that
+//                copy group g+1 over group g): 1.08 -> 1.24 ms at cfg2 (K=16), 0.76 -> 0.82 (K=8),
+//                2.35 -> 2.26 (K=32) -- the doubled flush code costs more than the copies;
+//  UNIFORM_SWITCH = 1  run switches behind one wave-uniform branch: no change (1.09 / 0.76 / 2.40 ms).
+#ifndef POINTOPS_LANE_PINGPONG
+#define POINTOPS_LANE_PINGPONG 0
+#endif
+#ifndef POINTOPS_LANE_UNIFORM_SWITCH
+#define POINTOPS_LANE_UNIFORM_SWITCH 0
+#endif
 
 template <int D, int KC, int NORM>
 __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
@@ -932,7 +943,23 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     }
     int r = 0;
     int cur = s_rows[0][lane].x, end = s_rows[0][lane].y;
-    auto next_record = [&]() -> int {  // index of the lane's next record, -1 when exhausted
+    auto next_record = [&]() __attribute__((always_inline)) -> int {  // index of the lane's next record, -1 when exhausted
+      // run switches are rare per lane (9 per ~170 records): keep them behind ONE wave-uniform
+      // branch so that the common step is branch-free (compare, two selects, add)
+#if POINTOPS_LANE_UNIFORM_SWITCH
+      if (__any(cur >= end && r < kLaneRows - 1)) {
+        while (cur >= end && r < kLaneRows - 1) {
+          ++r;
+          const int2 se = s_rows[r][lane];
+          cur = se.x;
+          end = se.y;
+        }
+      }
+      const bool ok = cur < end;
+      const int a = ok ? cur : -1;
+      cur += ok ? 1 : 0;
+      return a;
+#else
       while (cur >= end && r < kLaneRows - 1) {
         ++r;
         const int2 se = s_rows[r][lane];
@@ -940,13 +967,14 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
         end = se.y;
       }
       return cur < end ? cur++ : -1;
+#endif
     };
 
     TopKLex<KC> top;
     top.init();
     unsigned thr = thr0;
     int qn = 0;
-    auto flush = [&]() {
+    auto flush = [&]() __attribute__((always_inline)) {
       unsigned long long qk[kQueueCap];
 #pragma unroll
       for (int t = 0; t < kQueueCap; ++t) {
@@ -965,7 +993,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     };
 
     // software pipeline: the loads of group g+1 are issued before group g is processed
-    auto fetch = [&](float4 (&c)[kSub]) -> bool {
+    auto fetch = [&](float4 (&c)[kSub]) __attribute__((always_inline)) -> bool {
       int a[kSub];
 #pragma unroll
       for (int u = 0; u < kSub; ++u) a[u] = next_record();
@@ -977,11 +1005,8 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
       }
       return a[0] >= 0;
     };
-    float4 c[kSub];
-    bool more = fetch(c);
-    while (__any(more)) {
-      float4 nxt[kSub];
-      const bool more_next = fetch(nxt);
+    // two buffers in ping-pong (the loop body is written twice) so that no group is copied
+    auto process = [&](const float4 (&c)[kSub]) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < kSub; ++u) {
         float d;
@@ -1014,10 +1039,29 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
       if (kUseQueue) {
         if (__any(qn > kQueueCap - kSub)) flush();
       }
+    };
+#if POINTOPS_LANE_PINGPONG
+    float4 ca[kSub], cb[kSub];
+    bool more = fetch(ca);
+    while (__any(more)) {
+      more = fetch(cb);  // group g+1 in flight while group g is processed
+      process(ca);
+      if (!__any(more)) break;
+      more = fetch(ca);
+      process(cb);
+    }
+#else
+    float4 c[kSub];
+    bool more = fetch(c);
+    while (__any(more)) {
+      float4 nxt[kSub];
+      const bool more_next = fetch(nxt);  // group g+1 in flight while group g is processed
+      process(c);
 #pragma unroll
       for (int u = 0; u < kSub; ++u) c[u] = nxt[u];
       more = more_next;
     }
+#endif
     if (kUseQueue) flush();
 
     const unsigned kth_bits = top.worst_bits();

@@ -30,9 +30,11 @@ B, N = 32, 65536
 x = torch.from_numpy(synth.uniform_f32(71, (B, N, 3))).to(dev)
 y = torch.from_numpy(synth.uniform_f32(72, (B, N, 3))).to(dev)
 L = torch.full((B,), N, dtype=torch.int64, device=dev)
-for K in (1, 2, 4, 8, 16, 24, 32):
+KS = tuple(int(k) for k in os.environ.get("POINTOPS_SWEEP_KS", "1,2,4,8,16,24,32").split(","))
+SCALES = tuple(os.environ.get("POINTOPS_SWEEP_SCALES", "0.5,0.7,1.0,1.4,2.0,2.8,4.0").split(","))
+for K in KS:
     out = {}
-    for sc in ("0.5", "0.7", "1.0", "1.4", "2.0", "2.8", "4.0"):
+    for sc in SCALES:
         os.environ["POINTOPS_GRID_C_SCALE"] = sc
         out[sc] = round(timeit(lambda: _C.knn_points_idx(x, y, L, L, 2, K, 3)), 4)
     print(json.dumps({"K": K, "B": B, "N": N, "ms_by_scale": out}), flush=True)
