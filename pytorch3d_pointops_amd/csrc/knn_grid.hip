@@ -76,7 +76,8 @@ struct GridWs {
   float* edges;       // N * 3 * kEdgeStride
   int* cell_count;    // N * cell_cap   histogram, then scatter cursor
   int* cell_start;    // N * (cell_cap + 1)
-  float4* sorted;     // N * P2         (x, y, z, idx bits)
+  float4* sorted;     // N * (P2 + 1)   (x, y, z, idx bits); record P2 of every cloud is a NaN sentinel that
+                      //                exhausted lanes of the lane-private searches keep loading (never a candidate)
   int* blk_count;     // N * cell_cap
   int* blk_start;     // N * (cell_cap + 1)
   int* qlist;         // N * P1         query ids grouped by block
@@ -316,6 +317,8 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     g.B = B;
     s_g = g;
     ws.cloud[n] = g;
+    const float qnan = __uint_as_float(0x7fc00000u);
+    ws.sorted[(int64_t)n * (P2 + 1) + P2] = make_float4(qnan, qnan, qnan, 0.0f);
     ws.grid_flag[n] = g.use_grid;
     ws.fb_count[n] = 0;
     ws.fb2_count[n] = 0;
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __rest
         const int i = i0 + r * kBinBlock;
         const int pos = use_lds ? s_hist[bin[r]] + rank[r] : rank[r];
         if (IS_QUERY) ws.qlist[(int64_t)n * P + pos] = i;
-        else ws.sorted[(int64_t)n * P + pos] = make_float4(px[r], py[r], pz[r], __int_as_float(i));
+        else ws.sorted[(int64_t)n * (P + 1) + pos] = make_float4(px[r], py[r], pz[r], __int_as_float(i));
       }
     }
   }
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
     }
     __syncthreads();
     const int T = s_rowoff[nrows];  // records in the region
-    const float4* __restrict__ sp = sorted + (int64_t)n * P2;
+    const float4* __restrict__ sp = sorted + (int64_t)n * (P2 + 1);  // + 1: the cloud's NaN sentinel record
     const int* __restrict__ ql = qlist + (int64_t)n * P1;
 
     // record t of the flat stream -> its address (per lane); `rh` = a row at or before t's row
@@ -908,7 +911,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     const int Y0 = max(cy - 1, 0), Y1 = min(cy + 1, g.G[1] - 1);
     const int Z0 = max(cz - 1, 0), Z1 = min(cz + 1, g.G[2] - 1);
     const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
-    const float4* __restrict__ sp = sorted + (int64_t)n * P2;
+    const float4* __restrict__ sp = sorted + (int64_t)n * (P2 + 1);  // + 1: the cloud's NaN sentinel record
 
     // rigorous lower bound of every point outside the lane's cube (certification), known
     // before the walk: it also seeds the candidate threshold, since a query whose KC-th best
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
         cur = se.x;
         end = se.y;
       }
-      return cur < end ? cur++ : -1;
+      return cur < end ? cur++ : P2;  // exhausted: the NaN sentinel record
 #endif
     };
 
@@ -998,12 +1001,8 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
 #pragma unroll
       for (int u = 0; u < kSub; ++u) a[u] = next_record();
 #pragma unroll
-      for (int u = 0; u < kSub; ++u) {
-        const float qnan = __uint_as_float(0x7fc00000u);
-        c[u] = make_float4(qnan, qnan, qnan, 0.f);  // exhausted lanes: NaN distance, never passes
-        if (a[u] >= 0) c[u] = sp[a[u]];
-      }
-      return a[0] >= 0;
+      for (int u = 0; u < kSub; ++u) c[u] = sp[a[u]];  // unconditional: exhausted lanes read the sentinel
+      return a[0] != P2;
     };
     // two buffers in ping-pong (the loop body is written twice) so that no group is copied
     auto process = [&](const float4 (&c)[kSub]) __attribute__((always_inline)) {
@@ -1155,7 +1154,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
   const int sub = lane & (kQuadLanes - 1);
   const GridCloud g = clouds[n];
   const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
-  const float4* __restrict__ sp = sorted + (int64_t)n * P2;
+  const float4* __restrict__ sp = sorted + (int64_t)n * (P2 + 1);  // + 1: the cloud's NaN sentinel record
   const float* __restrict__ ed = edges + (int64_t)n * 3 * kEdgeStride;
 
   for (int base = blockIdx.x * kQuadQueries; base < cnt; base += gridDim.x * kQuadQueries) {
@@ -1204,7 +1203,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
         cur = se.x;
         end = se.y;
       }
-      return cur < end ? cur++ : -1;
+      return cur < end ? cur++ : P2;  // exhausted: the NaN sentinel record
     };
 
     TopKLex<KC> top;
@@ -1233,12 +1232,8 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
 #pragma unroll
       for (int u = 0; u < kQuadFetch; ++u) a[u] = next_record();
 #pragma unroll
-      for (int u = 0; u < kQuadFetch; ++u) {
-        const float qnan = __uint_as_float(0x7fc00000u);
-        c[u] = make_float4(qnan, qnan, qnan, 0.f);
-        if (a[u] >= 0) c[u] = sp[a[u]];
-      }
-      return a[0] >= 0;
+      for (int u = 0; u < kQuadFetch; ++u) c[u] = sp[a[u]];  // unconditional: exhausted lanes read the sentinel
+      return a[0] != P2;
     };
     float4 c[kQuadFetch];
     bool more = fetch(c);
@@ -1340,7 +1335,7 @@ __global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
   const GridCloud g = clouds[n];
   const float* __restrict__ ed = edges + (int64_t)n * 3 * kEdgeStride;
   const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
-  const float4* __restrict__ sp = sorted + (int64_t)n * P2;
+  const float4* __restrict__ sp = sorted + (int64_t)n * (P2 + 1);  // + 1: the cloud's NaN sentinel record
   const int kvalid = g.len2 < K ? g.len2 : K;
 
   for (int w = wave; w < cnt; w += kWavesPerCloud) {
@@ -1549,7 +1544,7 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
     const int Y0 = max(cy - 1, 0), Y1 = min(cy + 1, g.G[1] - 1);
     const int Z0 = max(cz - 1, 0), Z1 = min(cz + 1, g.G[2] - 1);
     const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
-    const float4* __restrict__ sp = sorted + (int64_t)n * P2;
+    const float4* __restrict__ sp = sorted + (int64_t)n * (P2 + 1);  // + 1: the cloud's NaN sentinel record
 
     // certification first: a lane whose cube cannot be proven to contain its ball does not walk
     const float* __restrict__ ed = edges + (int64_t)n * 3 * kEdgeStride;
@@ -1589,7 +1584,7 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
         cur = se.x;
         end = se.y;
       }
-      return cur < end ? cur++ : -1;
+      return cur < end ? cur++ : P2;  // exhausted: the NaN sentinel record
     };
 
     unsigned top[KC];  // ascending indices, kNone = empty
@@ -1619,12 +1614,8 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
 #pragma unroll
       for (int u = 0; u < kSub; ++u) a[u] = next_record();
 #pragma unroll
-      for (int u = 0; u < kSub; ++u) {
-        const float qnan = __uint_as_float(0x7fc00000u);
-        c[u] = make_float4(qnan, qnan, qnan, 0.f);  // exhausted lanes: NaN distance, never a hit
-        if (a[u] >= 0) c[u] = sp[a[u]];
-      }
-      return a[0] >= 0;
+      for (int u = 0; u < kSub; ++u) c[u] = sp[a[u]];  // unconditional: exhausted lanes read the sentinel
+      return a[0] != P2;
     };
     float4 c[kSub];
     bool more = fetch(c);
@@ -1746,7 +1737,7 @@ static size_t carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, f
   w.blk_count = (int*)take(sizeof(int) * (size_t)N * cap);  // adjacent to cell_count: one memset
   w.cell_start = (int*)take(sizeof(int) * (size_t)N * (cap + 1));
   w.blk_start = (int*)take(sizeof(int) * (size_t)N * (cap + 1));
-  w.sorted = (float4*)take(sizeof(float4) * (size_t)N * (size_t)P2);
+  w.sorted = (float4*)take(sizeof(float4) * (size_t)N * (size_t)(P2 + 1));
   w.qlist = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.fb_count = (int*)take(sizeof(int) * (size_t)N);
   w.fb_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
