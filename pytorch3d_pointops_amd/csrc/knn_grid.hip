@@ -862,12 +862,12 @@ constexpr int kLaneRows = 9;
 //  PINGPONG = 1  two candidate buffers with the loop body written twice (saves the 16 v_mov_b64 that
 //                copy group g+1 over group g): 1.08 -> 1.24 ms at cfg2 (K=16), 0.76 -> 0.82 (K=8),
 //                2.35 -> 2.26 (K=32) -- the doubled flush code costs more than the copies;
-//  UNIFORM_SWITCH = 1  run switches behind one wave-uniform branch: no change (1.09 / 0.76 / 2.40 ms).
+//  SWITCH = 1  run switches behind one wave-uniform branch: no change (1.09 / 0.76 / 2.40 ms); 0 = plain loop.
 #ifndef POINTOPS_LANE_PINGPONG
 #define POINTOPS_LANE_PINGPONG 0
 #endif
-#ifndef POINTOPS_LANE_UNIFORM_SWITCH
-#define POINTOPS_LANE_UNIFORM_SWITCH 0
+#ifndef POINTOPS_LANE_SWITCH
+#define POINTOPS_LANE_SWITCH 2
 #endif
 
 template <int D, int KC, int NORM>
@@ -949,7 +949,20 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     auto next_record = [&]() __attribute__((always_inline)) -> int {  // index of the lane's next record, -1 when exhausted
       // run switches are rare per lane (9 per ~170 records): keep them behind ONE wave-uniform
       // branch so that the common step is branch-free (compare, two selects, add)
-#if POINTOPS_LANE_UNIFORM_SWITCH
+#if POINTOPS_LANE_SWITCH == 2
+      // branch-free: at most ONE run switch per call (some lane of the wave switches on ~95 % of the
+      // calls, so a divergent loop here runs almost always, with one or two lanes); a lane whose new
+      // run is empty hands out the sentinel once and switches again on its next call
+      const bool need = cur >= end && r < kLaneRows - 1;
+      r += need ? 1 : 0;
+      const int2 se = s_rows[r][lane];
+      cur = need ? se.x : cur;
+      end = need ? se.y : end;
+      const bool ok = cur < end;
+      const int a = ok ? cur : P2;
+      cur += ok ? 1 : 0;
+      return a;
+#elif POINTOPS_LANE_SWITCH == 1
       if (__any(cur >= end && r < kLaneRows - 1)) {
         while (cur >= end && r < kLaneRows - 1) {
           ++r;
@@ -959,7 +972,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
         }
       }
       const bool ok = cur < end;
-      const int a = ok ? cur : -1;
+      const int a = ok ? cur : P2;
       cur += ok ? 1 : 0;
       return a;
 #else
@@ -1002,7 +1015,11 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
       for (int u = 0; u < kSub; ++u) a[u] = next_record();
 #pragma unroll
       for (int u = 0; u < kSub; ++u) c[u] = sp[a[u]];  // unconditional: exhausted lanes read the sentinel
-      return a[0] != P2;
+      // false once the lane has nothing left (a run switch may hand out the sentinel BEFORE real records)
+      bool real = false;
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) real = real || a[u] != P2;
+      return real || cur < end || r < kLaneRows - 1;
     };
     // two buffers in ping-pong (the loop body is written twice) so that no group is copied
     auto process = [&](const float4 (&c)[kSub]) __attribute__((always_inline)) {
