@@ -76,6 +76,11 @@ def cpu_baseline(p1, p2, sample_queries: int):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON result: libraries that write banners to fd 1 (RCCL prints
+    # its version block there when the first communicator is created) go to stderr for the whole run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -218,7 +223,8 @@ def main():
         except Exception as e:  # noqa: BLE001  (diagnostic only; never fails the bench line)
             result["sharded_chamfer"] = {"error": repr(e)[:200]}
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
