@@ -866,6 +866,9 @@ constexpr int kLaneRows = 9;
 #ifndef POINTOPS_LANE_PINGPONG
 #define POINTOPS_LANE_PINGPONG 0
 #endif
+#ifndef POINTOPS_LANE_FETCH
+#define POINTOPS_LANE_FETCH 4
+#endif
 #ifndef POINTOPS_LANE_SWITCH
 #define POINTOPS_LANE_SWITCH 2
 #endif
@@ -879,6 +882,9 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
   constexpr bool kUseQueue = KC >= 8 && (KC & (KC - 1)) == 0;
   constexpr int kQueueCap = KC < 16 ? KC : 16;
   constexpr int kSub = 4;
+  // gathers per lane and pipeline stage (processed kSub at a time): 8 only pays for the 32-slot lists
+  // (cfg2 size: K=32 2.27 -> 2.12 ms, but K=16 1.02 -> 1.09 ms, K=8 0.69 -> 0.72 ms)
+  constexpr int kFetch = KC >= 32 ? 8 : POINTOPS_LANE_FETCH;
   __shared__ unsigned long long s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
   __shared__ int2 s_rows[kLaneRows][kGridWave];  // per-lane (first record, end) of its 9 runs
 
@@ -1009,22 +1015,24 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     };
 
     // software pipeline: the loads of group g+1 are issued before group g is processed
-    auto fetch = [&](float4 (&c)[kSub]) __attribute__((always_inline)) -> bool {
-      int a[kSub];
+    auto fetch = [&](float4 (&c)[kFetch]) __attribute__((always_inline)) -> bool {
+      int a[kFetch];
 #pragma unroll
-      for (int u = 0; u < kSub; ++u) a[u] = next_record();
+      for (int u = 0; u < kFetch; ++u) a[u] = next_record();
 #pragma unroll
-      for (int u = 0; u < kSub; ++u) c[u] = sp[a[u]];  // unconditional: exhausted lanes read the sentinel
+      for (int u = 0; u < kFetch; ++u) c[u] = sp[a[u]];  // unconditional: exhausted lanes read the sentinel
       // false once the lane has nothing left (a run switch may hand out the sentinel BEFORE real records)
       bool real = false;
 #pragma unroll
-      for (int u = 0; u < kSub; ++u) real = real || a[u] != P2;
+      for (int u = 0; u < kFetch; ++u) real = real || a[u] != P2;
       return real || cur < end || r < kLaneRows - 1;
     };
     // two buffers in ping-pong (the loop body is written twice) so that no group is copied
-    auto process = [&](const float4 (&c)[kSub]) __attribute__((always_inline)) {
+    auto process = [&](const float4 (&c)[kFetch]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int u = 0; u < kSub; ++u) {
+     for (int u0 = 0; u0 < kFetch; u0 += kSub) {
+#pragma unroll
+      for (int u = u0; u < u0 + kSub; ++u) {
         float d;
         if (NORM == 1) {
           d = __builtin_fabsf(qx - c[u].x);
@@ -1055,9 +1063,10 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
       if (kUseQueue) {
         if (__any(qn > kQueueCap - kSub)) flush();
       }
+     }
     };
 #if POINTOPS_LANE_PINGPONG
-    float4 ca[kSub], cb[kSub];
+    float4 ca[kFetch], cb[kFetch];
     bool more = fetch(ca);
     while (__any(more)) {
       more = fetch(cb);  // group g+1 in flight while group g is processed
@@ -1067,14 +1076,14 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
       process(cb);
     }
 #else
-    float4 c[kSub];
+    float4 c[kFetch];
     bool more = fetch(c);
     while (__any(more)) {
-      float4 nxt[kSub];
+      float4 nxt[kFetch];
       const bool more_next = fetch(nxt);  // group g+1 in flight while group g is processed
       process(c);
 #pragma unroll
-      for (int u = 0; u < kSub; ++u) c[u] = nxt[u];
+      for (int u = 0; u < kFetch; ++u) c[u] = nxt[u];
       more = more_next;
     }
 #endif
