@@ -862,7 +862,9 @@ constexpr int kLaneRows = 9;
 //  PINGPONG = 1  two candidate buffers with the loop body written twice (saves the 16 v_mov_b64 that
 //                copy group g+1 over group g): 1.08 -> 1.24 ms at cfg2 (K=16), 0.76 -> 0.82 (K=8),
 //                2.35 -> 2.26 (K=32) -- the doubled flush code costs more than the copies;
-//  SWITCH = 1  run switches behind one wave-uniform branch: no change (1.09 / 0.76 / 2.40 ms); 0 = plain loop.
+//  SWITCH = 0  plain per-record loop over runs; 1 = the loop behind one wave-uniform branch (no change);
+//           2 = branch-free, one switch test per record (1.025 -> 1.011 ms); 3 (default) = one look at the
+//           next run per GROUP of four records (-> 0.99 ms; K=32: 2.12 -> 1.94 ms).
 #ifndef POINTOPS_LANE_PINGPONG
 #define POINTOPS_LANE_PINGPONG 0
 #endif
@@ -870,7 +872,7 @@ constexpr int kLaneRows = 9;
 #define POINTOPS_LANE_FETCH 4
 #endif
 #ifndef POINTOPS_LANE_SWITCH
-#define POINTOPS_LANE_SWITCH 2
+#define POINTOPS_LANE_SWITCH 3
 #endif
 
 template <int D, int KC, int NORM>
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
   // (cfg2 size: K=32 2.27 -> 2.12 ms, but K=16 1.02 -> 1.09 ms, K=8 0.69 -> 0.72 ms)
   constexpr int kFetch = KC >= 32 ? 8 : POINTOPS_LANE_FETCH;
   __shared__ unsigned long long s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
-  __shared__ int2 s_rows[kLaneRows][kGridWave];  // per-lane (first record, end) of its 9 runs
+  __shared__ int2 s_rows[kLaneRows + 1][kGridWave];  // per-lane (first record, end) of its 9 runs; row 9 = empty
 
   const int lane = threadIdx.x;
   const int total = chunk_prefix[N];
@@ -950,6 +952,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
       }
       s_rows[r][lane] = se;
     }
+    s_rows[kLaneRows][lane] = make_int2(0, 0);
     int r = 0;
     int cur = s_rows[0][lane].x, end = s_rows[0][lane].y;
     auto next_record = [&]() __attribute__((always_inline)) -> int {  // index of the lane's next record, -1 when exhausted
@@ -1015,10 +1018,33 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     };
 
     // software pipeline: the loads of group g+1 are issued before group g is processed
+    // four record indices at a time: ONE look at the next run per group instead of a run-switch test per
+    // record; a group may straddle into the next run once (a shorter next run hands out sentinels for
+    // the rest of the group, the following group moves on)
+    auto next_group = [&](int* a) __attribute__((always_inline)) {
+      const int2 nx = s_rows[r + 1][lane];
+      const int left = end - cur;
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) {
+        const int over = u - left;
+        const int b = nx.x + over;
+        a[u] = over < 0 ? cur + u : (b < nx.y ? b : P2);
+      }
+      const bool sw = left < kSub;
+      const int ncur = nx.x + (kSub - left);
+      cur = sw ? min(ncur, nx.y) : cur + kSub;
+      end = sw ? nx.y : end;
+      r += (sw && r < kLaneRows - 1) ? 1 : 0;
+    };
     auto fetch = [&](float4 (&c)[kFetch]) __attribute__((always_inline)) -> bool {
       int a[kFetch];
+#if POINTOPS_LANE_SWITCH == 3
+#pragma unroll
+      for (int u0 = 0; u0 < kFetch; u0 += kSub) next_group(a + u0);
+#else
 #pragma unroll
       for (int u = 0; u < kFetch; ++u) a[u] = next_record();
+#endif
 #pragma unroll
       for (int u = 0; u < kFetch; ++u) c[u] = sp[a[u]];  // unconditional: exhausted lanes read the sentinel
       // false once the lane has nothing left (a run switch may hand out the sentinel BEFORE real records)
