@@ -1036,6 +1036,8 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
       end = sw ? nx.y : end;
       r += (sw && r < kLaneRows - 1) ? 1 : 0;
     };
+    (void)next_record;
+    (void)next_group;
     auto fetch = [&](float4 (&c)[kFetch]) __attribute__((always_inline)) -> bool {
       int a[kFetch];
 #if POINTOPS_LANE_SWITCH == 3
@@ -1565,7 +1567,7 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
   constexpr int kSub = 4;
   constexpr unsigned kNone = 0xffffffffu;
   __shared__ unsigned s_queue[kQueueCap * kGridWave];
-  __shared__ int2 s_rows[kLaneRows][kGridWave];
+  __shared__ int2 s_rows[kLaneRows + 1][kGridWave];  // row 9 = empty
 
   const int lane = threadIdx.x;
   const int total = chunk_prefix[N];
@@ -1627,16 +1629,23 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
       }
       s_rows[r][lane] = se;
     }
+    s_rows[kLaneRows][lane] = make_int2(0, 0);
     int r = 0;
     int cur = s_rows[0][lane].x, end = s_rows[0][lane].y;
-    auto next_record = [&]() -> int {
-      while (cur >= end && r < kLaneRows - 1) {
-        ++r;
-        const int2 se = s_rows[r][lane];
-        cur = se.x;
-        end = se.y;
+    auto next_group = [&](int* a) __attribute__((always_inline)) {  // see knn_grid_lane_kernel
+      const int2 nx = s_rows[r + 1][lane];
+      const int left = end - cur;
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) {
+        const int over = u - left;
+        const int b = nx.x + over;
+        a[u] = over < 0 ? cur + u : (b < nx.y ? b : P2);
       }
-      return cur < end ? cur++ : P2;  // exhausted: the NaN sentinel record
+      const bool sw = left < kSub;
+      const int ncur = nx.x + (kSub - left);
+      cur = sw ? min(ncur, nx.y) : cur + kSub;
+      end = sw ? nx.y : end;
+      r += (sw && r < kLaneRows - 1) ? 1 : 0;
     };
 
     unsigned top[KC];  // ascending indices, kNone = empty
@@ -1661,13 +1670,16 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
       qn = 0;
       thr = top[KC - 1];
     };
-    auto fetch = [&](float4 (&c)[kSub]) -> bool {
+    auto fetch = [&](float4 (&c)[kSub]) __attribute__((always_inline)) -> bool {
       int a[kSub];
+      next_group(a);
+      bool real = false;
 #pragma unroll
-      for (int u = 0; u < kSub; ++u) a[u] = next_record();
-#pragma unroll
-      for (int u = 0; u < kSub; ++u) c[u] = sp[a[u]];  // unconditional: exhausted lanes read the sentinel
-      return a[0] != P2;
+      for (int u = 0; u < kSub; ++u) {
+        c[u] = sp[a[u]];  // unconditional: exhausted lanes read the sentinel
+        real = real || a[u] != P2;
+      }
+      return real || cur < end || r < kLaneRows - 1;
     };
     float4 c[kSub];
     bool more = fetch(c);
