@@ -53,7 +53,7 @@ namespace pointops {
 
 constexpr int kGMax = 1024;          // cells per dimension cap (edge table size)
 constexpr int kEdgeStride = kGMax + 2;
-constexpr int kSetupBlock = 256;
+constexpr int kSetupBlock = 1024;  // 3 x 1026 edge bisections per cloud
 constexpr int kScanBlock = 1024;
 constexpr int kGridWave = 64;
 constexpr int kNumXcd = 8;  // MI355X: 8 XCDs x 32 CUs, private 4 MB L2 each
@@ -134,7 +134,7 @@ __device__ float edge_bisect(int c, float lo, float hi, float inv_h, int G) {
 // pass 0: bounding boxes, all CUs.  fp32 min/max through order-preserving uint keys and
 // atomicMin / atomicMax (keys pre-set by grid_bbox_init_kernel).
 constexpr int kBboxBlock = 256;
-constexpr int kBboxPerThread = 32;
+constexpr int kBboxPerThread = 8;  // 2048 points per workgroup: enough workgroups to cover the latency of a 25 MB read
 
 __global__ void grid_bbox_init_kernel(unsigned* __restrict__ bbox, int N) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
