@@ -1139,8 +1139,9 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
 // <= 7 contiguous runs exactly like pass 5 (per-lane 16-byte gathers, eight in flight per
 // pipeline stage, stale-threshold queue, sorting-network merges), and two quad-permute
 // exchange steps merge the four sorted lists, after which every lane of the quad holds the
-// cube's KC best.  (8 or 16 lanes per query measured the same within noise: 1.16-1.19 ms
-// per cfg2 step against 1.23 ms without this pass.)  The same rigorous face bound
+// cube's KC best.  (Kernel time at cfg2 with 4 / 8 / 16 lanes per query: 83 / 96 / 97-107 us -- the pass
+// is throughput-bound, not bound by one wave's chain, so fewer, longer lanes win; 1.16 ms per step
+// against 1.23 ms when these queries went straight to the expanding wave search.)  The same rigorous face bound
 // decides; what is still uncertified (far-away queries) goes to the expanding wave search.
 // ---------------------------------------------------------------------------
 #ifndef POINTOPS_QUAD_LANES
