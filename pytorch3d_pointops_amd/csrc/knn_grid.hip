@@ -83,6 +83,7 @@ struct GridWs {
   int* qlist;         // N * P1         query ids grouped by block
   int* fb_count;      // N          queries the block search could not certify
   int* fb_list;       // N * P1
+  unsigned* fb_kth;   // N * P1     estimated KC-th distance (fp32 bits) of an uncertified query: picks the quad pass's cube
   int* fb2_count;     // N          queries the expanding search gave up on (whole-cloud scan)
   int* fb2_list;      // N * P1
   int* fb3_count;     // N          queries the radius-2 quad search could not certify (expanding search)
@@ -879,8 +880,9 @@ template <int D, int KC, int NORM>
 __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const int* __restrict__ chunk_prefix,
     const float* __restrict__ edges, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
-    const int* __restrict__ qlist, int* __restrict__ fb_count, int* __restrict__ fb_list, int cell_cap, int P1,
-    int P2, int K, int N, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+    const int* __restrict__ qlist, int* __restrict__ fb_count, int* __restrict__ fb_list,
+    unsigned* __restrict__ fb_kth, int cell_cap, int P1, int P2, int K, int N, int64_t* __restrict__ idxs,
+    float* __restrict__ dists) {
   constexpr bool kUseQueue = KC >= 8 && (KC & (KC - 1)) == 0;
   constexpr int kQueueCap = KC < 16 ? KC : 16;
   constexpr int kSub = 4;
@@ -1127,6 +1129,15 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
       } else {
         const int pos = atomicAdd(fb_count + n, 1);
         fb_list[(int64_t)n * P1 + pos] = qi;
+        // The seeded threshold admitted only the m < KC candidates below lb, so the KC-th best itself is
+        // unknown; hand the quad pass an ESTIMATE from the density they imply (m points inside radius
+        // sqrt(lb) -> KC points inside sqrt(lb) (KC/m)^(1/3)), 30 % up.  It only picks the cube to search.
+        int m = 0;
+#pragma unroll
+        for (int t = 0; t < KC; ++t) m += (unsigned)(top.key[t] >> 32) < 0x7f800000u ? 1 : 0;
+        const float est = m > 0 ? lb * __powf((float)KC / (float)m, NORM == 1 ? 0.33333f : 0.66667f) * 1.3f
+                                : __builtin_inff();
+        fb_kth[(int64_t)n * P1 + pos] = __float_as_uint(est);
       }
     }
   }
@@ -1194,8 +1205,9 @@ template <int D, int KC, int NORM>
 __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
     const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const float* __restrict__ edges,
     const int* __restrict__ cell_start, const float4* __restrict__ sorted, const int* __restrict__ fb_count,
-    const int* __restrict__ fb_list, int* __restrict__ fb3_count, int* __restrict__ fb3_list, int cell_cap, int P1,
-    int P2, int K, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+    const int* __restrict__ fb_list, const unsigned* __restrict__ fb_kth, int* __restrict__ fb3_count,
+    int* __restrict__ fb3_list, int cell_cap, int P1, int P2, int K, int64_t* __restrict__ idxs,
+    float* __restrict__ dists) {
   constexpr bool kUseQueue = KC >= 8 && (KC & (KC - 1)) == 0;
   constexpr int kQueueCap = KC < 16 ? KC : 16;
   constexpr int kSub = 4;
@@ -1220,9 +1232,20 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
     if (active) load_point3<D>(p1 + ((int64_t)n * P1 + qi) * D, qx, qy, qz);
     int cx, cy, cz;
     point_cells(g, qx, qy, qz, cx, cy, cz);
-    const int X0 = max(cx - 2, 0), X1 = min(cx + 2, g.G[0] - 1);
-    const int Y0 = max(cy - 2, 0), Y1 = min(cy + 2, g.G[1] - 1);
-    const int Z0 = max(cz - 2, 0), Z1 = min(cz + 2, g.G[2] - 1);
+    // The cube grows by one cell only past the faces of the 3x3x3 cube that the lane search's KC-th best
+    // reached (a superset search can only lower it, so the other faces stay certified): typically one
+    // face -> 36 cells instead of 125.  Whatever cube is searched is certified against ITS faces below.
+    const float kth3 = __uint_as_float(active ? fb_kth[(int64_t)n * P1 + w] : 0x7f800000u);
+    auto reach = [&](bool has, float bound) { return (has && !(kth3 < bound)) ? 2 : 1; };
+    const int ex0 = reach(cx - 1 > 0, face_bound<NORM>(qx - prev_float(ed[max(cx - 1, 0)])));
+    const int ex1 = reach(cx + 1 < g.G[0] - 1, face_bound<NORM>(ed[min(cx + 2, g.G[0])] - qx));
+    const int ey0 = reach(cy - 1 > 0, face_bound<NORM>(qy - prev_float(ed[kEdgeStride + max(cy - 1, 0)])));
+    const int ey1 = reach(cy + 1 < g.G[1] - 1, face_bound<NORM>(ed[kEdgeStride + min(cy + 2, g.G[1])] - qy));
+    const int ez0 = reach(cz - 1 > 0, face_bound<NORM>(qz - prev_float(ed[2 * kEdgeStride + max(cz - 1, 0)])));
+    const int ez1 = reach(cz + 1 < g.G[2] - 1, face_bound<NORM>(ed[2 * kEdgeStride + min(cz + 2, g.G[2])] - qz));
+    const int X0 = max(cx - ex0, 0), X1 = min(cx + ex1, g.G[0] - 1);
+    const int Y0 = max(cy - ey0, 0), Y1 = min(cy + ey1, g.G[1] - 1);
+    const int Z0 = max(cz - ez0, 0), Z1 = min(cz + ez1, g.G[2] - 1);
 
     const bool hx0 = X0 > 0, hx1 = X1 < g.G[0] - 1;
     const bool hy0 = Y0 > 0, hy1 = Y1 < g.G[1] - 1;
@@ -1242,7 +1265,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
       const int rr = sub + kQuadLanes * j;  // table entries >= 25 do not exist
       const int z = cz + kQuadDz[rr], y = cy + kQuadDy[rr];
       int2 se = make_int2(0, 0);
-      if (active && rr < 25 && z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1]) {
+      if (active && rr < 25 && z >= Z0 && z <= Z1 && y >= Y0 && y <= Y1) {
         const int rowbase = (z * g.G[1] + y) * g.G[0];
         se.x = cstart[rowbase + X0];
         se.y = cstart[rowbase + X1 + 1];
@@ -1806,6 +1829,7 @@ static size_t carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, f
   w.qlist = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.fb_count = (int*)take(sizeof(int) * (size_t)N);
   w.fb_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
+  w.fb_kth = (unsigned*)take(sizeof(unsigned) * (size_t)N * (size_t)P1);
   w.fb2_count = (int*)take(sizeof(int) * (size_t)N);
   w.fb2_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.fb3_count = (int*)take(sizeof(int) * (size_t)N);
@@ -1851,7 +1875,7 @@ static void launch_grid_lane(const KnnArgs& a, const GridWs& ws, int wgs) {
   hipLaunchKernelGGL((knn_grid_lane_kernel<D, KC, NORM>), dim3((unsigned)wgs), dim3(kGridWave), 0, a.stream, a.p1,
                      (const GridCloud*)ws.cloud, (const int*)ws.block_prefix, (const float*)ws.edges,
                      (const int*)ws.cell_start, (const float4*)ws.sorted, (const int*)ws.qlist, ws.fb_count,
-                     ws.fb_list, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
+                     ws.fb_list, ws.fb_kth, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
 }
 
 static bool grid_quad_mode(int P1) {
@@ -1871,8 +1895,9 @@ static void launch_grid_wave(const KnnArgs& a, const GridWs& ws) {
     wx = wx < 8 ? 8 : wx > 4096 ? 4096 : wx;
     hipLaunchKernelGGL((knn_grid_quad_kernel<D, KC, NORM>), dim3((unsigned)wx, (unsigned)a.N), dim3(kGridWave), 0,
                        a.stream, a.p1, (const GridCloud*)ws.cloud, (const float*)ws.edges, (const int*)ws.cell_start,
-                       (const float4*)ws.sorted, (const int*)ws.fb_count, (const int*)ws.fb_list, ws.fb3_count,
-                       ws.fb3_list, ws.cell_cap, a.P1, a.P2, a.K, a.idxs, a.dists);
+                       (const float4*)ws.sorted, (const int*)ws.fb_count, (const int*)ws.fb_list,
+                       (const unsigned*)ws.fb_kth, ws.fb3_count, ws.fb3_list, ws.cell_cap, a.P1, a.P2, a.K, a.idxs,
+                       a.dists);
   }
   hipLaunchKernelGGL((knn_grid_wave_kernel<D, KC, NORM>), dim3(kWaveKernelWgsPerCloud, (unsigned)a.N),
                      dim3(kWaveKernelBlock), 0, a.stream, a.p1, (const GridCloud*)ws.cloud, (const float*)ws.edges,
