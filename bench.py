@@ -83,8 +83,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--cpu-sample-queries", type=int, default=24576,
                     help="queries of the CPU-baseline sample (0 disables); ~10-20 s of CPU work")
     ap.add_argument("--version", type=int, default=-1, help="knn kernel family (-1 auto)")
