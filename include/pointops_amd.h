@@ -199,6 +199,17 @@ int pointops_chamfer_backward(const float* x, const float* y, const int64_t* idx
 int pointops_sample_pdf(const float* bins, const float* weights, float* outputs, int64_t batch,
                         int64_t n_bins, int64_t n_samples, float eps, void* stream);
 
+/*
+ * Per-point covariance of a gathered K-neighbourhood, fused -- device half of get_point_covariances
+ * (reference: functions/utils.py:111-153, which materialises a (N,P,K,D,D) tensor).
+ *   knn (N,P,K,D) fp32 -> cov (N,P,D,D): cov[a][b] = mean_k (x_k[a]-m[a])(x_k[b]-m[b]), m = mean_k x_k.
+ *   backward: grad_knn (N,P,K,D) = (G + G^T)(x_k - m) / K for G = grad_cov (N,P,D,D).  1 <= D <= 8.
+ */
+int pointops_point_covariances(const float* knn, int64_t N, int64_t P, int64_t K, int64_t D, float* cov,
+                               void* stream);
+int pointops_point_covariances_backward(const float* knn, const float* grad_cov, int64_t N, int64_t P, int64_t K,
+                                        int64_t D, float* grad_knn, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,8 @@ _SIGNATURES = {
                                                   _vp]),
     "pointops_chamfer_reduce": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),
     "pointops_sample_pdf": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp]),
+    "pointops_point_covariances": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "pointops_point_covariances_backward": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "pointops_chamfer_workspace_bytes": (_sz, [_i64, _i64]),
     "pointops_chamfer_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp, _int,
                                         _int, _vp, _vp, _sz, _vp]),
@@ -305,6 +307,34 @@ def sample_pdf(bins, weights, outputs, eps: float):
                                      outputs.shape[1], float(eps), _stream()),
             "sample_pdf",
         )
+
+
+# --- fused device half of get_point_covariances (functions/utils.py:111-153) -------
+POINT_COVARIANCES_MAX_D = 8
+
+
+def point_covariances(knn):
+    """knn (N,P,K,D) fp32 -> cov (N,P,D,D)."""
+    dev = _require_gpu(knn)
+    knn = knn.contiguous()
+    N, P, K, D = knn.shape
+    with torch.cuda.device(dev):
+        cov = torch.empty((N, P, D, D), dtype=torch.float32, device=dev)
+        _check(_lib.pointops_point_covariances(knn.data_ptr(), N, P, K, D, cov.data_ptr(), _stream()),
+               "point_covariances")
+    return cov
+
+
+def point_covariances_backward(knn, grad_cov):
+    dev = _require_gpu(knn, grad_cov)
+    knn, grad_cov = knn.contiguous(), grad_cov.contiguous()
+    N, P, K, D = knn.shape
+    with torch.cuda.device(dev):
+        grad_knn = torch.empty_like(knn)
+        _check(_lib.pointops_point_covariances_backward(knn.data_ptr(), grad_cov.data_ptr(), N, P, K, D,
+                                                        grad_knn.data_ptr(), _stream()),
+               "point_covariances_backward")
+    return grad_knn
 
 
 # --- device halves of knn_gather / masked_gather (functions/knn.py:200-250) -------

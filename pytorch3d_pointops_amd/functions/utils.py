@@ -7,6 +7,8 @@ from typing import Optional, Tuple, Union
 
 import torch
 
+from .. import _C
+
 
 def masked_gather(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """Gather ``points`` (N,P,D) at ``idx`` (N,K) or (N,P',K) where -1 marks padding.
@@ -75,8 +77,28 @@ def get_point_covariances(
         K=neighborhood_size,
         return_nn=True,
     ).knn
+    if (k_nearest_neighbors.is_cuda and k_nearest_neighbors.dtype == torch.float32
+            and 1 <= k_nearest_neighbors.shape[3] <= _C.POINT_COVARIANCES_MAX_D and k_nearest_neighbors.shape[2] >= 1):
+        # fused: no (N,P,K,D,D) tensor of outer products, closed-form backward (csrc/covariance.hip)
+        return _point_covariances.apply(k_nearest_neighbors), k_nearest_neighbors
     pt_mean = k_nearest_neighbors.mean(2, keepdim=True)
     central_diff = k_nearest_neighbors - pt_mean
     per_pt_cov = central_diff.unsqueeze(4) * central_diff.unsqueeze(3)
     covariances = per_pt_cov.mean(2)
     return covariances, k_nearest_neighbors
+
+
+class _point_covariances(torch.autograd.Function):
+    """cov[a][b] = mean_k (x_k[a] - m[a])(x_k[b] - m[b]); d/dx_k = (G + G^T)(x_k - m) / K."""
+
+    @staticmethod
+    def forward(ctx, knn):
+        knn = knn.contiguous()
+        ctx.save_for_backward(knn)
+        return _C.point_covariances(knn)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_cov):
+        (knn,) = ctx.saved_tensors
+        return _C.point_covariances_backward(knn, grad_cov.contiguous().float())

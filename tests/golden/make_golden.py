@@ -219,6 +219,30 @@ def gen_chamfer():
     save("chamfer", **out)
 
 
+def gen_covariances():
+    """get_point_covariances / wmean (functions/utils.py:68-153): forward values and the gradient w.r.t. the
+    points through knn_gather and the covariance arithmetic."""
+    from pytorch3d_pointops.functions.utils import get_point_covariances, wmean
+
+    out = {}
+    for name, (N, P, D, K, lens) in {"d3_k8": (2, 120, 3, 8, [120, 57]), "d2_k5": (1, 90, 2, 5, [90]),
+                                     "d3_k16_ties": (1, 150, 3, 16, [150])}.items():
+        pts = cases.lattice(811, N, P, D, levels=6) if "ties" in name else cases.cloud(810 + D + K, (N, P, D))
+        x = T(pts).requires_grad_(True)
+        cov, knn = get_point_covariances(x, T(np.array(lens), torch.int64), K)
+        out[name + "/cov"] = cov.detach().numpy()
+        out[name + "/knn"] = knn.detach().numpy()
+        gc = T(cases.grad_for("cov" + name, tuple(cov.shape)))
+        gk = T(cases.grad_for("knn" + name, tuple(knn.shape)))
+        ((cov * gc).sum() + (knn * gk).sum()).backward()
+        out[name + "/grad_points"] = x.grad.numpy()
+    xw = T(cases.cloud(820, (2, 40, 3)))
+    w = T(synth.uniform_f32(821, (2, 40)))
+    out["wmean/weighted"] = wmean(xw, w).numpy()
+    out["wmean/plain"] = wmean(xw).numpy()
+    save("covariances", **out)
+
+
 def gen_sample_pdf():
     from pytorch3d_pointops.functions.sample_pdf import sample_pdf as ref_sample_pdf
 
@@ -273,6 +297,9 @@ def gen_big():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--only" in sys.argv:  # regenerate one fixture: --only covariances
+        globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
+        sys.exit(0)
     gen_knn()
     gen_knn_backward()
     gen_ball_query()
@@ -281,5 +308,6 @@ if __name__ == "__main__":
     gen_gather()
     gen_chamfer()
     gen_sample_pdf()
+    gen_covariances()
     if "--big" in sys.argv:
         gen_big()

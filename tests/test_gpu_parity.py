@@ -500,6 +500,52 @@ def test_packed_padded_trailing_dims(dev):
     assert np.array_equal(padded_to_packed(q, G(first, dev), 15, max_size_dim=2).cpu().numpy(), g["trailing/roundtrip"])
 
 
+# ------------------------------------------------------------------ get_point_covariances / wmean
+@pytest.mark.parametrize("name", ["d3_k8", "d2_k5", "d3_k16_ties"])
+def test_get_point_covariances(dev, name):
+    """Fused covariance kernel + closed-form backward against the reference's composed torch ops
+    (functions/utils.py:111-153; goldens from the reference itself), values and gradients within 1e-5."""
+    from pytorch3d_pointops_amd.functions.utils import get_point_covariances
+
+    g = load_golden("covariances")
+    N, P, D, K, lens = {"d3_k8": (2, 120, 3, 8, [120, 57]), "d2_k5": (1, 90, 2, 5, [90]),
+                        "d3_k16_ties": (1, 150, 3, 16, [150])}[name]
+    pts = cases.lattice(811, N, P, D, levels=6) if "ties" in name else cases.cloud(810 + D + K, (N, P, D))
+    x = G(pts, dev).requires_grad_(True)
+    cov, knn = get_point_covariances(x, G(np.array(lens), dev), K)
+    assert np.array_equal(knn.detach().cpu().numpy(), g[name + "/knn"])
+    assert close(cov.detach().cpu().numpy(), g[name + "/cov"])
+    gc = G(cases.grad_for("cov" + name, tuple(cov.shape)), dev)
+    gk = G(cases.grad_for("knn" + name, tuple(knn.shape)), dev)
+    ((cov * gc).sum() + (knn * gk).sum()).backward()
+    assert close(x.grad.cpu().numpy(), g[name + "/grad_points"])
+
+
+def test_point_covariances_wide_and_wmean(dev):
+    """D up to 8 (runtime-D kernel) against the composed torch expression on the same neighbourhoods;
+    wmean against the reference's values."""
+    from pytorch3d_pointops_amd import _C
+    from pytorch3d_pointops_amd.functions.utils import wmean
+
+    for D, K in ((1, 3), (5, 7), (8, 12)):
+        knn = G(cases.cloud(2100 + D, (2, 300, K, D)), dev).requires_grad_(True)
+        m = knn.mean(2, keepdim=True)
+        cd = knn - m
+        ref = (cd.unsqueeze(4) * cd.unsqueeze(3)).mean(2)
+        gc = G(cases.grad_for("covw%d" % D, tuple(ref.shape)), dev)
+        (ref * gc).sum().backward()
+        cov = _C.point_covariances(knn.detach())
+        gk = _C.point_covariances_backward(knn.detach(), gc)
+        assert close(cov.cpu().numpy(), ref.detach().cpu().numpy())
+        assert close(gk.cpu().numpy(), knn.grad.cpu().numpy())
+    g = load_golden("covariances")
+    from pytorch3d_pointops_amd import synth
+    xw = G(cases.cloud(820, (2, 40, 3)), dev)
+    w = G(synth.uniform_f32(821, (2, 40)), dev)
+    assert close(wmean(xw, w).cpu().numpy(), g["wmean/weighted"])
+    assert close(wmean(xw).cpu().numpy(), g["wmean/plain"])
+
+
 # ------------------------------------------------------------------ chamfer
 def _chamfer_call(dev, inp, v, as_leaf=True):
     from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance

@@ -40,7 +40,7 @@ def emit(name, ms, mn, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ops", default="bq,fps,chamfer,packed,gather,knn_bwd,knn_small")
+    ap.add_argument("--ops", default="bq,fps,chamfer,packed,gather,cov,knn_bwd,knn_small")
     args = ap.parse_args()
     ops = args.ops.split(",")
     dev = torch.device("cuda:0")
@@ -115,6 +115,19 @@ def main():
             emit(f"knn_gather backward B=32 N=65536 K=16 U=3 [{mode}]", ms, mn,
                  algo_GBs=(Bg * Pg * Kg * (8 + 12) + Bg * Pg * 12) / ms / 1e6)
         del os.environ["POINTOPS_GATHER_BWD_MODE"]
+    if "cov" in ops:
+        Bv, Pv, Kv = 8, 65536, 16
+        kn = torch.from_numpy(synth.uniform_f32(91, (Bv, Pv, Kv, 3))).to(dev)
+
+        def composed():
+            m = kn.mean(2, keepdim=True)
+            cd = kn - m
+            return (cd.unsqueeze(4) * cd.unsqueeze(3)).mean(2)
+
+        ms, mn = timeit(lambda: _C.point_covariances(kn))
+        emit("point_covariances (fused) B=8 N=65536 K=16 D=3", ms, mn, algo_GBs=(Bv * Pv * (Kv * 12 + 36)) / ms / 1e6)
+        ms, mn = timeit(composed)
+        emit("point_covariances (composed torch ops, reference form)", ms, mn)
     if "knn_bwd" in ops:
         Bb, Pb, Kb = 32, 65536, 16
         a = torch.from_numpy(synth.uniform_f32(81, (Bb, Pb, 3))).to(dev)
