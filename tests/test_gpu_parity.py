@@ -174,6 +174,28 @@ def test_knn_grid_adversarial(dev, oracle, name):
     assert torch.equal(r2.idx, r.idx) and torch.equal(r2.dists, r.dists)
 
 
+@pytest.mark.parametrize("mode", ["quad", "block", "noquad"])
+@pytest.mark.parametrize("name", ["clustered", "lattice_ties", "disjoint_far", "half_in_cluster", "k32", "k1", "d2"])
+def test_knn_grid_alternative_passes(dev, oracle, monkeypatch, mode, name):
+    """The passes the automatic choice only takes on large clouds (the radius-2 quad search needs >= 32768
+    queries per cloud) or never (block-shared search), forced on the adversarial distributions."""
+    from pytorch3d_pointops_amd.functions import knn_points
+
+    if mode == "quad":
+        monkeypatch.setenv("POINTOPS_GRID_QUAD", "1")
+    elif mode == "noquad":
+        monkeypatch.setenv("POINTOPS_GRID_QUAD", "0")
+    else:
+        monkeypatch.setenv("POINTOPS_GRID_MODE", "block")
+    p1, p2, K = _grid_adversarial_cases()[name]
+    l1 = np.array([p1.shape[1], p1.shape[1] // 3])
+    l2 = np.array([p2.shape[1], max(K - 2, 1)])
+    r = knn_points(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), K=K, version=3)
+    oi, od = oracle.knn_points_idx(p1, p2, l1, l2, 2, K)
+    assert np.array_equal(r.idx.cpu().numpy(), oi)
+    assert np.array_equal(bits(r.dists.cpu().numpy()), bits(od))
+
+
 def test_knn_default_lengths_and_empty(dev, oracle):
     from pytorch3d_pointops_amd.functions import knn_points
 
