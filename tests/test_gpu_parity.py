@@ -423,6 +423,28 @@ def test_ball_query_grid_vs_oracle(dev, oracle, monkeypatch, radius, K, D):
     assert torch.equal(idx, idx0) and torch.equal(d.view(torch.int32), d0.view(torch.int32))
 
 
+@pytest.mark.parametrize("name", ["clustered", "planar", "collinear", "all_identical", "lattice_ties", "offset_1e3",
+                                  "tiny_scale", "disjoint_far", "half_in_cluster", "d2", "d1"])
+def test_ball_query_grid_adversarial(dev, oracle, monkeypatch, name):
+    """Grid path of the ball query forced on (also past the device-side density test) for degenerate and
+    skewed distributions: flat / collinear / identical points, lattices whose distances sit exactly on
+    radius^2, offsets, tiny scales, disjoint clouds, dense clusters."""
+    from pytorch3d_pointops_amd import _C
+
+    p1, p2, _ = _grid_adversarial_cases()[name]
+    scale = float(np.abs(p2).max()) if name == "tiny_scale" else 1.0
+    radius = 0.25 * scale if name == "lattice_ties" else 0.06 * scale
+    l1 = np.array([p1.shape[1], p1.shape[1] // 3])
+    l2 = np.array([p2.shape[1], 5])
+    monkeypatch.setenv("POINTOPS_BALL_GRID", "1")
+    monkeypatch.setenv("POINTOPS_BALL_FACTOR", "0")  # always the grid where one can be built
+    for K in (4, 20):
+        idx, d = _C.ball_query(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), K, radius)
+        oi, od = oracle.ball_query(p1, p2, l1, l2, K, radius)
+        assert np.array_equal(idx.cpu().numpy(), oi), (name, K)
+        assert np.array_equal(bits(d.cpu().numpy()), bits(od)), (name, K)
+
+
 # ------------------------------------------------------------------ FPS
 @pytest.mark.parametrize("name", sorted(cases.fps_cases()))
 def test_sample_farthest_points(dev, oracle, name):
