@@ -239,8 +239,8 @@ def test_knn_backward(dev, oracle, name):
 
 
 @pytest.mark.parametrize("mode,split", [("tiled", None), ("tiled", "3"), ("atomic", None)])
-@pytest.mark.parametrize("D,norm", [(3, 2), (3, 1), (2, 2), (4, 2), (1, 2)])
-def test_knn_backward_modes(dev, oracle, monkeypatch, mode, split, D, norm):
+@pytest.mark.parametrize("D,norm,K", [(3, 2, 8), (3, 1, 8), (2, 2, 8), (4, 2, 8), (1, 2, 8), (3, 2, 1), (3, 2, 3), (3, 2, 21)])
+def test_knn_backward_modes(dev, oracle, monkeypatch, mode, split, D, norm, K):
     """grad_p2 through the LDS-tile kernel (several tiles per cloud, ragged clouds, an empty cloud,
     row splits that meet with atomics) and through the device-atomic kernel: both against the
     oracle's CPU loop (knn_cpu.cpp:75-128) on the SAME neighbour table."""
@@ -249,7 +249,7 @@ def test_knn_backward_modes(dev, oracle, monkeypatch, mode, split, D, norm):
     monkeypatch.setenv("POINTOPS_KNN_BWD_MODE", mode)
     if split:
         monkeypatch.setenv("POINTOPS_KNN_BWD_SPLIT", split)
-    N, P1, P2, K = 3, 2500, 30000, 8
+    N, P1, P2 = 3, 2500, 30000
     p1 = cases.cloud(1500 + D, (N, P1, D))
     p2 = cases.cloud(1510 + D, (N, P2, D))
     l1 = np.array([P1, 1777, 0])
