@@ -859,13 +859,19 @@ __device__ __forceinline__ unsigned seed_threshold(float lb, bool whole) {
 // and the certification bound are the same, evaluated on the lane's own cube.
 // ---------------------------------------------------------------------------
 constexpr int kLaneRows = 9;
-// Two measured-and-dropped forms of the lane search stay selectable at compile time (tools/build_variant.py):
+// Pipeline forms of the lane search, selectable at compile time (tools/build_variant.py):
+//  PIPE = 1 (default)  in-place: a candidate's registers are reloaded with the next group's record as soon as
+//                its distance and index are taken -- no buffer copies (K=1 0.46 -> 0.45, K=8 0.69 -> 0.67,
+//                K=32 1.94 -> 1.89 ms at cfg2 size; K=16 unchanged); PIPE = 0: two buffers, group g+1 copied over g;
 //  PINGPONG = 1  two candidate buffers with the loop body written twice (saves the 16 v_mov_b64 that
 //                copy group g+1 over group g): 1.08 -> 1.24 ms at cfg2 (K=16), 0.76 -> 0.82 (K=8),
 //                2.35 -> 2.26 (K=32) -- the doubled flush code costs more than the copies;
 //  SWITCH = 0  plain per-record loop over runs; 1 = the loop behind one wave-uniform branch (no change);
 //           2 = branch-free, one switch test per record (1.025 -> 1.011 ms); 3 (default) = one look at the
 //           next run per GROUP of four records (-> 0.99 ms; K=32: 2.12 -> 1.94 ms).
+#ifndef POINTOPS_LANE_PIPE
+#define POINTOPS_LANE_PIPE 1
+#endif
 #ifndef POINTOPS_LANE_PINGPONG
 #define POINTOPS_LANE_PINGPONG 0
 #endif
@@ -1095,7 +1101,74 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
       }
      }
     };
-#if POINTOPS_LANE_PINGPONG
+#if POINTOPS_LANE_PIPE == 1
+    // In-place pipeline: a candidate's registers are reloaded with the record of the NEXT group as soon
+    // as its distance and index have been taken, so a group's gathers fly during the rest of the
+    // previous group (threshold tests, pushes, flush) and nothing is copied between buffers.
+    auto indices = [&](int* a) __attribute__((always_inline)) -> bool {
+#pragma unroll
+      for (int u0 = 0; u0 < kFetch; u0 += kSub) next_group(a + u0);
+      bool real = false;
+#pragma unroll
+      for (int u = 0; u < kFetch; ++u) real = real || a[u] != P2;
+      return real || cur < end || r < kLaneRows - 1;
+    };
+    float4 c[kFetch];
+    int a0[kFetch];
+    bool more = indices(a0);
+#pragma unroll
+    for (int u = 0; u < kFetch; ++u) c[u] = sp[a0[u]];
+    while (__any(more)) {
+      int an[kFetch];
+      const bool more_next = indices(an);
+#pragma unroll
+      for (int u0 = 0; u0 < kFetch; u0 += kSub) {
+        float dd[kSub];
+        int ii[kSub];
+#pragma unroll
+        for (int u = u0; u < u0 + kSub; ++u) {
+          float d;
+          if (NORM == 1) {
+            d = __builtin_fabsf(qx - c[u].x);
+            if (D > 1) d = d + __builtin_fabsf(qy - c[u].y);
+            if (D > 2) d = d + __builtin_fabsf(qz - c[u].z);
+          } else {
+            const float dx = qx - c[u].x;
+            d = dx * dx;
+            if (D > 1) {
+              const float dy = qy - c[u].y;
+              d = d + dy * dy;
+            }
+            if (D > 2) {
+              const float dz = qz - c[u].z;
+              d = d + dz * dz;
+            }
+          }
+          dd[u - u0] = d;
+          ii[u - u0] = __float_as_int(c[u].w);
+          c[u] = sp[an[u]];  // next group's record into the same registers
+        }
+#pragma unroll
+        for (int t = 0; t < kSub; ++t) {
+          if (kUseQueue) {
+            if (__float_as_uint(dd[t]) <= thr) {
+              s_queue[qn * kGridWave + lane] = TopKLex<KC>::make(dd[t], ii[t]);
+              ++qn;
+            }
+          } else if (__float_as_uint(dd[t]) <= min(top.worst_bits(), thr0)) {
+            const unsigned long long key = TopKLex<KC>::make(dd[t], ii[t]);
+            if (key < top.key[KC - 1]) top.insert(key);
+          }
+        }
+        if (kUseQueue) {
+          if (__any(qn > kQueueCap - kSub)) flush();
+        }
+      }
+      more = more_next;
+    }
+    (void)process;
+    (void)fetch;
+#elif POINTOPS_LANE_PINGPONG
     float4 ca[kFetch], cb[kFetch];
     bool more = fetch(ca);
     while (__any(more)) {
