@@ -875,6 +875,9 @@ constexpr int kLaneRows = 9;
 #ifndef POINTOPS_LANE_PINGPONG
 #define POINTOPS_LANE_PINGPONG 0
 #endif
+#ifndef POINTOPS_LANE_FETCH32
+#define POINTOPS_LANE_FETCH32 8
+#endif
 #ifndef POINTOPS_LANE_FETCH
 #define POINTOPS_LANE_FETCH 4
 #endif
@@ -894,7 +897,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
   constexpr int kSub = 4;
   // gathers per lane and pipeline stage (processed kSub at a time): 8 only pays for the 32-slot lists
   // (cfg2 size: K=32 2.27 -> 2.12 ms, but K=16 1.02 -> 1.09 ms, K=8 0.69 -> 0.72 ms)
-  constexpr int kFetch = KC >= 32 ? 8 : POINTOPS_LANE_FETCH;
+  constexpr int kFetch = KC >= 32 ? POINTOPS_LANE_FETCH32 : POINTOPS_LANE_FETCH;
   __shared__ unsigned long long s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
   __shared__ int2 s_rows[kLaneRows + 1][kGridWave];  // per-lane (first record, end) of its 9 runs; row 9 = empty
 
