@@ -879,7 +879,7 @@ constexpr int kLaneRows = 9;
 #define POINTOPS_LANE_FETCH32 8
 #endif
 #ifndef POINTOPS_LANE_FETCH
-#define POINTOPS_LANE_FETCH 4
+#define POINTOPS_LANE_FETCH 8
 #endif
 #ifndef POINTOPS_LANE_SWITCH
 #define POINTOPS_LANE_SWITCH 3
@@ -895,8 +895,9 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
   constexpr bool kUseQueue = KC >= 8 && (KC & (KC - 1)) == 0;
   constexpr int kQueueCap = KC < 16 ? KC : 16;
   constexpr int kSub = 4;
-  // gathers per lane and pipeline stage (processed kSub at a time): 8 only pays for the 32-slot lists
-  // (cfg2 size: K=32 2.27 -> 2.12 ms, but K=16 1.02 -> 1.09 ms, K=8 0.69 -> 0.72 ms)
+  // gathers per lane and pipeline stage (processed kSub at a time).  With the in-place pipeline eight win or
+  // tie everywhere (cfg2 size: K=8 0.67 -> 0.64, K=4 0.54 -> 0.52, K=32 2.07 -> 1.88 ms, K=16 unchanged); with the
+  // two-buffer pipeline they only paid for the 32-slot lists.
   constexpr int kFetch = KC >= 32 ? POINTOPS_LANE_FETCH32 : POINTOPS_LANE_FETCH;
   __shared__ unsigned long long s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
   __shared__ int2 s_rows[kLaneRows + 1][kGridWave];  // per-lane (first record, end) of its 9 runs; row 9 = empty
