@@ -1868,9 +1868,9 @@ static void grid_tuning(int K, float* c_target, int* B) {
   // the search keeps the KC >= K best and certifies the KC-th, so size the cells for KC
   // points per cell: measured optimum at B=32, N=65536 (profiles/r01_grid_tuning.txt): 0.4 KC for the
   // queue/network variants (KC >= 8; fewer candidates per region at ~0.6 % uncertified queries),
-  // 0.5 KC for the direct-insert variants
+  // 0.625 KC for the direct-insert variants (re-swept after the walk got cheaper: K=4 0.53 -> 0.51 ms)
   const int kc = grid_kc(K);
-  float c = (kc >= 8 ? 0.4f : 0.5f) * (float)kc;
+  float c = (kc >= 8 ? 0.4f : 0.625f) * (float)kc;
   if (const char* e = getenv("POINTOPS_GRID_C_SCALE")) c *= (float)atof(e);  // tuning experiments only
   if (c < 1.0f) c = 1.0f;
   int b = (int)lround(cbrt(64.0 / (double)c));  // ~64 queries (one wave) per block
