@@ -78,6 +78,15 @@ struct TopKLex {
     return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
   }
   __device__ __forceinline__ unsigned worst_bits() const { return (unsigned)(key[KC - 1] >> 32); }
+  // distance bits of the K-th best (1 <= K <= KC, runtime): what a query needs certified
+  __device__ __forceinline__ unsigned kth_bits(int K) const {
+    unsigned b = (unsigned)(key[KC - 1] >> 32);
+    if (K < KC) {  // wave-uniform branch; a select chain (indexing the register array by K would go through scratch)
+#pragma unroll
+      for (int t = 0; t < KC - 1; ++t) b = (t == K - 1) ? (unsigned)(key[t] >> 32) : b;
+    }
+    return b;
+  }
   // requires k < key[KC-1]
   __device__ __forceinline__ void insert(unsigned long long k) {
     bool lt_hi = true;  // k < key[i] for the slot above the current one

@@ -817,7 +817,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_kernel(
       if (kUseQueue) flush();
       // Acceptance: the KC-th best (KC >= K: conservative) against the rigorous lower bound
       // of every point that was not visited.
-      const unsigned kth_bits = top.worst_bits();
+      const unsigned kth_bits = top.kth_bits(K);  // the K-th best, not the list's last slot
       float lb = __builtin_inff();
       if (hx0) lb = fminf(lb, face_bound<NORM>(qx - fx0));
       if (hx1) lb = fminf(lb, face_bound<NORM>(fx1 - qx));
@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
 #endif
     if (kUseQueue) flush();
 
-    const unsigned kth_bits = top.worst_bits();
+    const unsigned kth_bits = top.kth_bits(K);  // the K-th best, not the list's last slot
     const bool full = kth_bits < 0x7f800000u;
     const bool ok = whole || (full && __uint_as_float(kth_bits) < lb);
     if (active) {
@@ -1208,11 +1208,11 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
         fb_list[(int64_t)n * P1 + pos] = qi;
         // The seeded threshold admitted only the m < KC candidates below lb, so the KC-th best itself is
         // unknown; hand the quad pass an ESTIMATE from the density they imply (m points inside radius
-        // sqrt(lb) -> KC points inside sqrt(lb) (KC/m)^(1/3)), 30 % up.  It only picks the cube to search.
+        // sqrt(lb) -> K points inside sqrt(lb) (K/m)^(1/3)), 30 % up.  It only picks the cube to search.
         int m = 0;
 #pragma unroll
         for (int t = 0; t < KC; ++t) m += (unsigned)(top.key[t] >> 32) < 0x7f800000u ? 1 : 0;
-        const float est = m > 0 ? lb * __powf((float)KC / (float)m, NORM == 1 ? 0.33333f : 0.66667f) * 1.3f
+        const float est = m > 0 ? lb * __powf(fmaxf((float)K / (float)m, 1.0f), NORM == 1 ? 0.33333f : 0.66667f) * 1.3f
                                 : __builtin_inff();
         fb_kth[(int64_t)n * P1 + pos] = __float_as_uint(est);
       }
@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
     if (kQuadLanes >= 8) dpp_merge<KC, kDppHalfMirror>(top);
     if (kQuadLanes >= 16) dpp_merge<KC, kDppMirror>(top);
 
-    const unsigned kth_bits = top.worst_bits();
+    const unsigned kth_bits = top.kth_bits(K);  // the K-th best, not the list's last slot
     const bool full = kth_bits < 0x7f800000u;
     const bool ok = whole || (full && __uint_as_float(kth_bits) < lb);
     if (active && sub == 0) {
@@ -1865,12 +1865,12 @@ static int grid_kc(int K) {
 }
 
 static void grid_tuning(int K, float* c_target, int* B) {
-  // the search keeps the KC >= K best and certifies the KC-th, so size the cells for KC
-  // points per cell: measured optimum at B=32, N=65536 (profiles/r01_grid_tuning.txt): 0.4 KC for the
-  // queue/network variants (KC >= 8; fewer candidates per region at ~0.6 % uncertified queries),
-  // 0.625 KC for the direct-insert variants (re-swept after the walk got cheaper: K=4 0.53 -> 0.51 ms)
+  // the search keeps the KC >= K best but certifies the K-th, so the cells are sized for K points:
+  // measured optimum at B=32, N=65536 (profiles/r01_grid_tuning.txt): 0.4 K for the queue/network
+  // variants (KC >= 8; fewer candidates per cube at ~1 % uncertified queries), 0.625 K for the
+  // direct-insert variants (re-swept after the walk got cheaper: K=4 0.53 -> 0.51 ms)
   const int kc = grid_kc(K);
-  float c = (kc >= 8 ? 0.4f : 0.625f) * (float)kc;
+  float c = (kc >= 8 ? 0.4f : 0.625f) * (float)K;
   if (const char* e = getenv("POINTOPS_GRID_C_SCALE")) c *= (float)atof(e);  // tuning experiments only
   if (c < 1.0f) c = 1.0f;
   int b = (int)lround(cbrt(64.0 / (double)c));  // ~64 queries (one wave) per block
