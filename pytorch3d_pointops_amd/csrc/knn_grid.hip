@@ -384,14 +384,17 @@ __device__ __forceinline__ void point_cells(const GridCloud& g, float x, float y
 //
 // Scattered device-scope atomics run at only ~2e10/s chip-wide (they execute at the
 // memory side, one 64-byte request each), so a workgroup first bins its tile of
-// 1024 x 16 points in an LDS histogram (fast LDS atomics, which also hand every point
+// 1024 x 8 points in an LDS histogram (fast LDS atomics, which also hand every point
 // its rank inside the (tile, bin) group) and then touches each non-empty global
 // counter ONCE: count pass  global[bin] += n_tile ;  scatter pass  base = start[bin] +
 // atomicAdd(cursor[bin], n_tile), position = base + rank.  Clouds with more bins than
 // the LDS table holds (kBinLdsBins) use one global atomic per point.
 // ---------------------------------------------------------------------------
 constexpr int kBinBlock = 1024;
-constexpr int kBinPerThread = 16;
+#ifndef POINTOPS_BIN_PER_THREAD
+#define POINTOPS_BIN_PER_THREAD 8  // tile of 8192 points: 4096 / 8192 / 16384 / 32768 measured 0.988 / 0.969 / 0.987 / 1.125 ms per cfg2 step (chamfer cfg4: 1.14 / 1.13 / 1.22 / 1.66 ms)
+#endif
+constexpr int kBinPerThread = POINTOPS_BIN_PER_THREAD;
 constexpr int kBinTile = kBinBlock * kBinPerThread;
 static_assert(kBinLdsBinsSetup == 40000, "keep in sync");
 constexpr int kBinLdsBins = 40000;  // 156 KiB of LDS: the whole CU's LDS, one workgroup per CU
