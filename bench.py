@@ -2,45 +2,139 @@
 """bench.py -- headline benchmark: knn_points B=32 N=M=65536 K=16 D=3 fp32 per GPU
 (BASELINE.json configs[1]; metric "Mpoint-pairs/s (+ %HBM roofline) knn_points ...").
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py                                   # 1 GPU
+    python bench.py --gpus 4 --steps 20 --warmup 5    # spawns 4 ranks itself (one process per GPU, RCCL)
+    python bench.py --gpus 8 --scaling strong         # BASELINE.json configs[4]: B=256 split over the ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # the same ranks, external launcher
 
 A "step" is one pass of the hot path (one `knn_points_idx` call through the C ABI,
 outputs allocated inside the timed region as the op does) over one resident batch of
-32 synthetic clouds per GPU.  With N GPUs every rank owns its own 32 clouds (batch
-sharding, no data-path collective -- clouds are independent), so
-scaling is "weak" and `value` is the whole-job aggregate.
+synthetic clouds.  Clouds are independent, so ranks own disjoint
+clouds and the data path has no collective:
+  --scaling weak   (default) every rank owns 32 clouds       -> per-GPU work fixed;
+  --scaling strong 256 clouds in total, 256/N per rank       -> total work fixed.
+`value` is the whole-job aggregate in BRUTE-FORCE-EQUIVALENT point pairs (sum_n len1*len2 per
+step, the nominal all-pairs count of SURVEY.md section 8d -- the grid search evaluates only a
+small fraction of them, exactly).
 
-One JSON line on rank 0.  `roofline` prices the dominant kernel (the KNN scan)
-against the HBM roofline with ALGORITHMIC bytes (SURVEY.md section 8d:
-4*D*(P1+P2) + P1*K*12 bytes per cloud = 452,984,832 B per launch) over the HIP-event
-duration of the launch, measured live on the launch stream.  `cpu_baseline` is the
-reference's own CPU kernel (oracle/_ref, kind "reference") or the C oracle (kind
-"port") timed single-threaded on a bounded sample of the same workload.
+One JSON line on rank 0.  `roofline` prices the op against the HBM roofline with ALGORITHMIC
+bytes (4*D*(P1+P2) + P1*K*12 bytes per cloud = 452,984,832 B per 32-cloud
+launch) over the HIP-event duration of the launch, measured live on the launch stream;
+`roofline.traffic` and `roofline.valu_issue` come from committed rocprofv3 counter passes of this
+same command and are nulled when the kernel sources changed since they were taken.
+`cpu_baseline` is the reference's own CPU kernel (oracle/_ref, kind "reference") or the C oracle
+(kind "port") timed on a bounded sample of the same workload.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B, P, K, D = 32, 65536, 16, 3
+B_PER_GPU, B_STRONG_TOTAL, P, K, D = 32, 256, 65536, 16, 3
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 7.86e13 fp32 lane-ops/s (SURVEY.md section 8d)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0  # wave64 VALU instructions/s: 1024 SIMD-32s, 2 cycles per instruction
 
 
 def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--cpu-sample-queries", type=int, default=24576,
+                    help="queries of the CPU-baseline sample (0 disables); ~10-20 s of CPU work")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the CPU kernel on every host core (query blocks over a thread pool)")
+    ap.add_argument("--version", type=int, default=-1, help="knn kernel family (-1 auto)")
+    ap.add_argument("--chamfer-steps", type=int, default=3,
+                    help="multi-rank runs: timed sharded chamfer fwd+bwd steps after the KNN region (0 disables)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with N > 1 and no torchrun environment spawns the N ranks
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args) -> int:
+    """Parent of a self-launched multi-GPU run.  It never touches the GPU (device_count() does not
+    initialise HIP on this image), starts one fresh interpreter per rank, relays rank 0's JSON line and
+    returns non-zero if any rank fails."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        log(f"--gpus {args.gpus} needs {args.gpus} visible GPUs, this machine has {have}: not launching")
+        return 2
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
+                "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(rcs):
+        log(f"rank exit codes {rcs}: failing")
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return 1
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------
+def kernel_source_digest():
+    """sha256 over the HIP sources: ties committed counter profiles to the code they were measured on
+    (there is no .git on the GPU box)."""
+    import glob
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "pytorch3d_pointops_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(name, version):
+    """profiles/<name> if it was measured on the current kernel sources (and the auto kernel family), else None."""
+    path = os.path.join(ROOT, "profiles", name)
+    if version != -1 or not os.path.exists(path):
+        return None
+    try:
+        j = json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return None
+    if j.get("kernel_source_digest") != kernel_source_digest():
+        return None
+    return j
+
+
 def make_clouds(first_cloud: int, n_clouds: int):
+    import numpy as np
+
     from pytorch3d_pointops_amd import synth
 
     p1 = np.empty((n_clouds, P, D), np.float32)
@@ -52,50 +146,62 @@ def make_clouds(first_cloud: int, n_clouds: int):
     return p1, p2
 
 
-def cpu_baseline(p1, p2, sample_queries: int):
-    """Reference CPU kernel (or its C port) on `sample_queries` queries of cloud 0 vs all of p2[0]."""
+def cpu_baseline(p1, p2, sample_queries: int, threads: int = 1):
+    """Reference CPU kernel (or its C port) on `sample_queries` queries of cloud 0 vs all of p2[0];
+    `threads` > 1 splits the queries into blocks over a thread pool (the kernels release the GIL)."""
+    import numpy as np
+
     from oracle.oracle import Oracle, load_ref
 
     ora = load_ref() or Oracle()
-    q = np.ascontiguousarray(p1[:1, :sample_queries])
     r = np.ascontiguousarray(p2[:1])
-    l1 = np.array([sample_queries])
     l2 = np.array([P])
+    blocks = np.array_split(np.arange(sample_queries), threads)
+
+    def run(ix):
+        q = np.ascontiguousarray(p1[:1, ix[0]:ix[-1] + 1])
+        return ora.knn_points_idx(q, r, np.array([len(ix)]), l2, 2, K)[0]
+
     t0 = time.perf_counter()
-    idx, _ = ora.knn_points_idx(q, r, l1, l2, 2, K)
+    if threads == 1:
+        parts = [run(blocks[0])]
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(threads) as ex:
+            parts = list(ex.map(run, blocks))
     dt = time.perf_counter() - t0
+    idx = np.concatenate(parts, axis=1)
     pairs = float(sample_queries) * P
     return {
         "value": pairs / dt / 1e6,
         "unit": "Mpoint-pairs/s",
-        "cores": 1,
+        "cores": threads,
         "kind": ora.kind,
         "sample": f"{sample_queries} queries of cloud 0 x all {P} points of p2[0], K={K} "
-                  f"({pairs:.3g} pairs, {dt:.1f} s, single thread; host has {os.cpu_count()} cpus)",
+                  f"({pairs:.3g} pairs, {dt:.1f} s, {threads} thread(s); host has {os.cpu_count()} cpus)",
     }, idx
 
 
 def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+
     # stdout carries exactly ONE line, the JSON result: libraries that write banners to fd 1 (RCCL prints
     # its version block there when the first communicator is created) go to stderr for the whole run
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--cpu-sample-queries", type=int, default=24576,
-                    help="queries of the CPU-baseline sample (0 disables); ~10-20 s of CPU work")
-    ap.add_argument("--version", type=int, default=-1, help="knn kernel family (-1 auto)")
-    args = ap.parse_args()
+
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -105,17 +211,27 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     from pytorch3d_pointops_amd import _C
+    from pytorch3d_pointops_amd.sharded import shard_bounds
 
-    p1_h, p2_h = make_clouds(rank * B, B)
+    if args.scaling == "strong":
+        first, last = shard_bounds(B_STRONG_TOTAL, world)[rank]
+        total_clouds = B_STRONG_TOTAL
+    else:
+        first, last = rank * B_PER_GPU, (rank + 1) * B_PER_GPU
+        total_clouds = B_PER_GPU * world
+    nb = last - first
+    p1_h, p2_h = make_clouds(first, nb)
     p1 = torch.from_numpy(p1_h).to(dev)
     p2 = torch.from_numpy(p2_h).to(dev)
-    l1 = torch.full((B,), P, dtype=torch.int64, device=dev)
-    l2 = torch.full((B,), P, dtype=torch.int64, device=dev)
+    l1 = torch.full((nb,), P, dtype=torch.int64, device=dev)
+    l2 = torch.full((nb,), P, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
-    log(f"rank {rank}/{world}: inputs resident ({p1.numel() * 8 / 1e6:.1f} MB)")
+    log(f"rank {rank}/{world}: clouds [{first}, {last}) resident ({p1.numel() * 8 / 1e6:.1f} MB)")
 
     def step():
         return _C.knn_points_idx(p1, p2, l1, l2, 2, K, args.version)
@@ -146,22 +262,29 @@ def main():
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     avg_kern_s = float(np.mean(kern_ms)) / 1e3
 
-    pairs_per_step_rank = float(B) * P * P
-    total_pairs = pairs_per_step_rank * args.steps * world
+    total_pairs = float(total_clouds) * P * P * args.steps
     value = total_pairs / elapsed / 1e6
-    algo_bytes = B * (4 * D * (P + P) + P * K * 12)  # 452,984,832 B per launch
+    algo_bytes = nb * (4 * D * (P + P) + P * K * 12)  # 452,984,832 B per 32-cloud launch
     achieved = algo_bytes / avg_kern_s / 1e9
 
-    # HBM-side bytes per step from the committed rocprofv3 PMC passes of this same command
-    # (tools/pmc_traffic.py; separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)
-    traffic, traffic_src = None, None
-    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tj) and args.version == -1:
-        try:
-            traffic = float(json.load(open(tj))["traffic_bytes_per_step"])
-            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
-        except Exception:  # noqa: BLE001
-            traffic = None
+    # counter passes of this same command (tools/profile_round.sh): HBM-side bytes per launch (FETCH_SIZE /
+    # WRITE_SIZE, separate passes) and executed VALU instructions per launch (SQ_INSTS_VALU)
+    weak1 = args.scaling == "weak" or world == 8
+    tj = committed_counters("pmc_traffic.json", args.version) if weak1 else None
+    sq = committed_counters("sq_counters.json", args.version) if weak1 else None
+    valu_issue = None
+    if sq is not None:
+        insts = float(sq["valu_insts_per_launch"])
+        valu_issue = {
+            "insts_per_launch": insts,
+            "achieved_ginst_s": insts / avg_kern_s / 1e9,
+            "peak_ginst_s": VALU_ISSUE_PEAK / 1e9,
+            "frac": insts / avg_kern_s / VALU_ISSUE_PEAK,
+            "valu_busy_frac_dominant_kernel": sq.get("valu_busy_frac_dominant_kernel"),
+            "source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU ... pass of bench.py)",
+            "note": "wave64 VALU instructions executed by all kernels of one launch / time / (1024 SIMDs x 1.2 G "
+                    "instructions/s); the exact search is bound by VALU issue, not by HBM (SURVEY.md section 8d)",
+        }
 
     result = {
         "metric": "Mpoint-pairs/s (+ %HBM roofline) knn_points B=32 N=65536 K=16 @1/2/4/8 GPU",
@@ -172,14 +295,19 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "knn_points B=32 N=M=65536 K=16 D=3 fp32 per GPU (BASELINE.json configs[1]); "
-                        "splitmix64 uniform [0,1)^3 clouds, p1 != p2, full lengths, norm=2",
-            "clouds_per_gpu": B,
+            "workload": ("knn_points B=32 N=M=65536 K=16 D=3 fp32 per GPU (BASELINE.json configs[1])"
+                         if args.scaling == "weak" else
+                         f"knn_points B={B_STRONG_TOTAL} N=M=65536 K=16 D=3 fp32 split over {world} GPU(s) "
+                         "(BASELINE.json configs[4])")
+                        + "; splitmix64 uniform [0,1)^3 clouds, p1 != p2, full lengths, norm=2",
+            "clouds_per_gpu": nb,
+            "clouds_total": total_clouds,
+            "pairs": "brute-force-equivalent: sum_n len1[n]*len2[n] per step (the grid search visits ~0.3 % of them)",
             "sharding": "batch-sharded clouds, one process per GPU, no data-path collective",
             "kernel_version": args.version,
         },
@@ -189,14 +317,14 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "traffic_source": traffic_src,
+            "traffic": float(tj["traffic_bytes_per_step"]) if tj else None,
+            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
+                              if tj else None,
             "kernel": "knn_points_idx = grid build (bbox, histogram, scan, counting sort) + knn_grid_lane_kernel "
-                      "(dominant, ~75 % of the step) + exact fallbacks; `achieved` prices the WHOLE op, "
-                      "HIP-event timed on the launch stream",
+                      "(dominant) + exact fallbacks; `achieved` prices the WHOLE op, HIP-event timed on the launch stream",
             "algorithmic_bytes_per_launch": algo_bytes,
             "avg_launch_ms": avg_kern_s * 1e3,
-            "valu_frac_9ops_per_pair": pairs_per_step_rank * 9 / avg_kern_s / VALU_LANE_OPS,
+            "valu_issue": valu_issue,
         },
     }
 
@@ -207,21 +335,36 @@ def main():
         # the checker doubles as a parity probe of the benchmarked output
         gpu_idx = out[0][0, : args.cpu_sample_queries].cpu().numpy()
         result["cpu_baseline"]["idx_equal_on_sample"] = bool(np.array_equal(gpu_idx, cpu_idx[0]))
-    if use_dist:
-        # Outside the timed region: the path's one real exchange -- chamfer's batch reduction over
-        # clouds sharded across ranks = one RCCL all_gather of the per-cloud loss vectors.
-        try:
-            from pytorch3d_pointops_amd.sharded import sharded_chamfer_distance
+        if args.cpu_all_cores:
+            n = os.cpu_count() or 1
+            cb_all, _ = cpu_baseline(p1_h, p2_h, args.cpu_sample_queries * min(n, 8), threads=n)
+            result["cpu_baseline_all_cores"] = cb_all
+    if use_dist and args.chamfer_steps > 0:
+        # Outside the KNN region: the path's one real exchange -- chamfer's batch reduction over clouds
+        # sharded across ranks = one RCCL all_gather of the per-cloud loss vectors (fwd + bwd timed).
+        from pytorch3d_pointops_amd.sharded import sharded_chamfer_distance
 
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            loss, _ = sharded_chamfer_distance(p1, p2, B * world)
-            torch.cuda.synchronize()
-            result["sharded_chamfer"] = {"clouds_total": B * world, "loss": float(loss),
-                                         "first_call_ms": (time.perf_counter() - t1) * 1e3,
-                                         "collective": "one RCCL all_gather of (B/G,) fp32 per-cloud losses"}
-        except Exception as e:  # noqa: BLE001  (diagnostic only; never fails the bench line)
-            result["sharded_chamfer"] = {"error": repr(e)[:200]}
+        x = p1.clone().requires_grad_(True)
+        y = p2.clone().requires_grad_(True)
+
+        def cham():
+            loss, _ = sharded_chamfer_distance(x, y, total_clouds, cloud_counts=[e - s for s, e in (
+                shard_bounds(B_STRONG_TOTAL, world) if args.scaling == "strong"
+                else [(r * B_PER_GPU, (r + 1) * B_PER_GPU) for r in range(world)])])
+            loss.backward()
+            return loss
+
+        loss = cham()  # warm-up (communicator creation, autograd graph)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.chamfer_steps):
+            loss = cham()
+        torch.cuda.synchronize()
+        barrier()
+        dt = (time.perf_counter() - t1) / args.chamfer_steps
+        result["sharded_chamfer"] = {"clouds_total": total_clouds, "loss": float(loss), "fwd_bwd_ms_per_step": dt * 1e3,
+                                     "collective": "one RCCL all_gather of the per-cloud fp32 loss vectors per step"}
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(result) + "\n").encode())

@@ -107,6 +107,19 @@ def _contig(t, name):
         raise RuntimeError(f"{name} must be contiguous")
 
 
+def _f32c(t, name):
+    """fp32 + contiguous view of a device tensor whose data pointer goes to a kernel."""
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected scalar type Float for {name}")
+    return t.contiguous()
+
+
+def _i64c(t, name):
+    if t.dtype != torch.int64:
+        raise RuntimeError(f"{name} must be int64")
+    return t.contiguous()
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -340,14 +353,15 @@ def point_covariances_backward(knn, grad_cov):
 # --- device halves of knn_gather / masked_gather (functions/knn.py:200-250) -------
 def gather_neighbors(x, idx, lengths=None):
     dev = _require_gpu(x, idx) if lengths is None else _require_gpu(x, idx, lengths)
-    x, idx = x.contiguous(), idx.contiguous()
+    x, idx = _f32c(x, "x"), _i64c(idx, "idx")
+    lengths = _i64c(lengths, "lengths") if lengths is not None else None
     N, M, U = x.shape
     _, L, K = idx.shape
     with torch.cuda.device(dev):
         out = torch.empty((N, L, K, U), dtype=torch.float32, device=dev)
         _check(
             _lib.pointops_gather_neighbors(x.data_ptr(), idx.data_ptr(),
-                                           lengths.contiguous().data_ptr() if lengths is not None else None,
+                                           lengths.data_ptr() if lengths is not None else None,
                                            N, M, U, L, K, out.data_ptr(), _stream()),
             "gather_neighbors",
         )
@@ -355,15 +369,16 @@ def gather_neighbors(x, idx, lengths=None):
 
 
 def gather_neighbors_backward(grad_out, idx, lengths, M: int):
-    dev = _require_gpu(grad_out, idx)
-    grad_out, idx = grad_out.contiguous(), idx.contiguous()
+    dev = _require_gpu(grad_out, idx) if lengths is None else _require_gpu(grad_out, idx, lengths)
+    grad_out, idx = _f32c(grad_out, "grad_out"), _i64c(idx, "idx")
+    lengths = _i64c(lengths, "lengths") if lengths is not None else None
     N, L, K, U = grad_out.shape
     with torch.cuda.device(dev):
         grad_x = torch.empty((N, M, U), dtype=torch.float32, device=dev)
         _check(
             _lib.pointops_gather_neighbors_backward(
                 grad_out.data_ptr(), idx.data_ptr(),
-                lengths.contiguous().data_ptr() if lengths is not None else None, N, M, U, L, K,
+                lengths.data_ptr() if lengths is not None else None, N, M, U, L, K,
                 grad_x.data_ptr(), _stream()),
             "gather_neighbors_backward",
         )
@@ -372,14 +387,17 @@ def gather_neighbors_backward(grad_out, idx, lengths, M: int):
 
 def chamfer_reduce(dists, lengths, weights, mean: bool):
     """dists (N,P) fp32 -> (N,) per-cloud masked sum [* weights] [/ max(len,1)]."""
-    dev = _require_gpu(dists, lengths)
-    dists, lengths = dists.contiguous(), lengths.contiguous()
+    dev = _require_gpu(dists, lengths) if weights is None else _require_gpu(dists, lengths, weights)
+    dists, lengths = _f32c(dists, "dists"), _i64c(lengths, "lengths")
+    weights = _f32c(weights, "weights") if weights is not None else None
     N, P = dists.shape
+    if lengths.shape != (N,) or (weights is not None and weights.shape != (N,)):
+        raise RuntimeError("chamfer_reduce: lengths / weights must have shape (N,)")
     with torch.cuda.device(dev):
         out = torch.empty((N,), dtype=torch.float32, device=dev)
         _check(
             _lib.pointops_chamfer_reduce(dists.data_ptr(), lengths.data_ptr(),
-                                         weights.contiguous().data_ptr() if weights is not None else None,
+                                         weights.data_ptr() if weights is not None else None,
                                          N, P, int(bool(mean)), out.data_ptr(), _stream()),
             "chamfer_reduce",
         )
@@ -398,13 +416,34 @@ def _ptr_array(tensors):
     return arr
 
 
+def _check_chamfer_shapes(N, P1, P2, idx, x_lengths, y_lengths, weights, x_feats, y_feats):
+    if len(x_feats) != len(y_feats) or len(x_feats) > CHAMFER_MAX_FEATURES:
+        raise RuntimeError(f"chamfer: at most {CHAMFER_MAX_FEATURES} feature pairs")
+    if idx.shape != (N, P1) or x_lengths.shape != (N,) or y_lengths.shape != (N,):
+        raise RuntimeError("chamfer: idx must be (N, P1) and the lengths (N,)")
+    if weights is not None and weights.shape != (N,):
+        raise RuntimeError("chamfer: weights must have shape (N,)")
+    for a, b in zip(x_feats, y_feats):
+        if a.dim() != 3 or b.dim() != 3 or a.shape[:2] != (N, P1) or b.shape[:2] != (N, P2) \
+                or a.shape[2] != b.shape[2] or not 1 <= a.shape[2] <= CHAMFER_MAX_CHANNELS:
+            raise RuntimeError("chamfer: features must be (N, P1, C) / (N, P2, C) with 1 <= C <= "
+                               f"{CHAMFER_MAX_CHANNELS}")
+
+
 def chamfer_forward(dists, idx, x_lengths, y_lengths, weights, x_feats, y_feats, abs_cosine: bool, mean: bool):
     """dists (N,P1) fp32 and idx (N,P1) int64 of the K=1 search -> out (1+F, N): row 0 the point term,
     row 1+f the cosine term of feature f, each already weighted and (for "mean") length-normalised."""
-    dev = _require_gpu(dists, idx, x_lengths, y_lengths)
+    opt = [weights] if weights is not None else []
+    dev = _require_gpu(dists, idx, x_lengths, y_lengths, *opt, *x_feats, *y_feats)
+    dists, idx = _f32c(dists, "dists"), _i64c(idx, "idx")
+    x_lengths, y_lengths = _i64c(x_lengths, "x_lengths"), _i64c(y_lengths, "y_lengths")
+    weights = _f32c(weights, "weights") if weights is not None else None
+    x_feats = [_f32c(t, "x_feats") for t in x_feats]
+    y_feats = [_f32c(t, "y_feats") for t in y_feats]
     N, P1 = dists.shape
     F = len(x_feats)
     P2 = y_feats[0].shape[1] if F else 0
+    _check_chamfer_shapes(N, P1, P2, idx, x_lengths, y_lengths, weights, x_feats, y_feats)
     C = (ctypes.c_int64 * max(F, 1))(*[int(t.shape[2]) for t in x_feats])
     with torch.cuda.device(dev):
         out = torch.empty((1 + F, N), dtype=torch.float32, device=dev)
@@ -424,10 +463,20 @@ def chamfer_forward(dists, idx, x_lengths, y_lengths, weights, x_feats, y_feats,
 def chamfer_backward(x, y, idx, x_lengths, y_lengths, weights, grad_out, norm: int, x_feats, y_feats,
                      abs_cosine: bool, mean: bool):
     """Closed-form gradients of chamfer_forward's outputs: returns (grad_x, grad_y, [grad_x_feat], [grad_y_feat])."""
-    dev = _require_gpu(x, y, idx, grad_out)
+    opt = [weights] if weights is not None else []
+    dev = _require_gpu(x, y, idx, grad_out, x_lengths, y_lengths, *opt, *x_feats, *y_feats)
+    x, y, grad_out = _f32c(x, "x"), _f32c(y, "y"), _f32c(grad_out, "grad_out")
+    idx = _i64c(idx, "idx")
+    x_lengths, y_lengths = _i64c(x_lengths, "x_lengths"), _i64c(y_lengths, "y_lengths")
+    weights = _f32c(weights, "weights") if weights is not None else None
+    x_feats = [_f32c(t, "x_feats") for t in x_feats]
+    y_feats = [_f32c(t, "y_feats") for t in y_feats]
     N, P1, D = x.shape
     P2 = y.shape[1]
     F = len(x_feats)
+    if y.shape[0] != N or y.shape[2] != D or grad_out.shape != (1 + F, N):
+        raise RuntimeError("chamfer_backward: inconsistent shapes")
+    _check_chamfer_shapes(N, P1, P2, idx, x_lengths, y_lengths, weights, x_feats, y_feats)
     C = (ctypes.c_int64 * max(F, 1))(*[int(t.shape[2]) for t in x_feats])
     with torch.cuda.device(dev):
         grad_x = torch.empty_like(x)

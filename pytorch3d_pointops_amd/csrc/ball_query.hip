@@ -18,9 +18,8 @@
 // (expected points per ball), and this kernel then scans only what is left: whole clouds whose
 // flag is 0, and the listed (uncertified) queries of the others.
 #include "common.h"
+#include "debug.h"
 #include "knn_grid.h"
-
-#include <cstdlib>
 
 namespace pointops {
 
@@ -149,10 +148,9 @@ using namespace pointops;
 // grid path considered (the per-cloud decision is made on the device): D <= 3, K <= 64, clouds large
 // enough for the build passes to pay
 static bool ball_grid_candidate(int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K) {
-  if (const char* e = getenv("POINTOPS_BALL_GRID")) {  // 0 = never, 1 = whenever the shape allows (tests)
-    if (e[0] == '0') return false;
-    if (e[0] == '1') return D <= 3 && K <= 64 && N < 65536 && P2 <= (1 << 20) && N > 0 && P1 > 0 && P2 > 0;
-  }
+  const long force = debug_knob("ball_grid", -1);  // 0 = never, 1 = whenever the shape allows (tests)
+  if (force == 0) return false;
+  if (force == 1) return D <= 3 && K <= 64 && N < 65536 && P2 <= (1 << 20) && N > 0 && P1 > 0 && P2 > 0;
   return D <= 3 && K <= 64 && N < 65536 && P2 >= 4096 && P2 <= (1 << 20) &&
          (double)N * (double)P1 * (double)P2 >= (double)(1LL << 27);
 }

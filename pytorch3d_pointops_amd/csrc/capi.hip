@@ -1,7 +1,10 @@
 // capi.hip -- library identification + thread-local error string.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
+#include "debug.h"
 
 namespace pointops {
 static thread_local char g_err[512] = "";
@@ -10,6 +13,33 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// value of `key` inside POINTOPS_DEBUG="k=v,k=v": pointer to v (terminated by ',' or NUL), or nullptr
+static const char* debug_value(const char* key) {
+  const char* e = getenv("POINTOPS_DEBUG");
+  if (!e) return nullptr;
+  const size_t kl = strlen(key);
+  while (*e) {
+    const char* end = strchr(e, ',');
+    const size_t len = end ? (size_t)(end - e) : strlen(e);
+    if (len > kl && strncmp(e, key, kl) == 0 && e[kl] == '=') return e + kl + 1;
+    if (!end) break;
+    e = end + 1;
+  }
+  return nullptr;
+}
+long debug_knob(const char* key, long dflt) {
+  const char* v = debug_value(key);
+  return v ? strtol(v, nullptr, 10) : dflt;
+}
+double debug_knob_f(const char* key, double dflt) {
+  const char* v = debug_value(key);
+  return v ? strtod(v, nullptr) : dflt;
+}
+char debug_knob_c(const char* key) {
+  const char* v = debug_value(key);
+  return (v && *v != ',') ? *v : 0;
 }
 }  // namespace pointops
 

@@ -16,6 +16,7 @@
 #include <float.h>
 
 #include "common.h"
+#include "debug.h"
 
 namespace pointops {
 
@@ -34,10 +35,12 @@ template <int DT>
 __global__ __launch_bounds__(kFpsBlock) void fps_kernel(
     const float* __restrict__ points, const int64_t* __restrict__ lengths,
     const int64_t* __restrict__ Ks, const int64_t* __restrict__ start_idxs, int P, int Drt,
-    int max_K, int64_t* __restrict__ idxs, float* __restrict__ min_dist) {
+    int max_K, int64_t* __restrict__ idxs, float* __restrict__ min_dist, const unsigned* __restrict__ only_flagged) {
   const int D = DT > 0 ? DT : Drt;
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
+  // repair pass behind the cluster kernel: only the clouds whose exchange timed out are redone here
+  if (only_flagged != nullptr && only_flagged[n] == 0u) return;
   const int lane = tid & (kWave - 1);
   const int wave = tid / kWave;
   int len = (int)lengths[n];
@@ -147,38 +150,95 @@ __global__ __launch_bounds__(kFpsBlock) void fps_kernel(
 // v2: register-resident clusters.  A cloud is split over G workgroups (G = ceil(P /
 // (PPT*1024)), up to one workgroup per CU); every lane keeps its PPT points AND their
 // running min-distances in VGPRs, so an iteration touches no memory except the
-// exchange: each workgroup reduces its local argmax and publishes it with ONE relaxed
-// agent-scope 8-byte store into its own slot of the (cloud, iteration) row -- key =
-// distance bits << 32 | ~index, never 0; the key IS the message, so there is no flag, no
-// counter and no fence (cdna guide G16, R2 "the data is the flag") -- then wave 0 polls the
-// G slots of the row (relaxed agent-scope loads + s_sleep) until all are non-zero and
-// takes their maximum: the largest distance and, on ties, the LOWEST index, i.e.
+// exchange: each workgroup reduces its local argmax and publishes it with ONE 8-byte store into its
+// own slot of the (cloud, iteration) row -- key = distance bits << 32 | ~index, never 0; the key IS
+// the message, so there is no flag, no counter and no fence (cdna guide G16, R2 "the data is the
+// flag") -- then wave 0 polls the G slots of the row (L1-bypassing loads + s_sleep) until all are
+// non-zero and takes their maximum: the largest distance and, on ties, the LOWEST index, i.e.
 // std::max_element's first maximum.  Rows are per iteration, zeroed by a memset node before
-// the launch; only agent-scope atomics ever touch them, the points are read-only input.  All workgroups of the grid are resident by
-// construction (grid <= number of CUs, one 1024-lane workgroup per CU), and every spin
-// is bounded.
+// the launch; the points are read-only input.
+//
+// Placement (MODE, debug knob fps_mode).  Workgroups are dealt round-robin over the 8 XCDs, so blocks
+// b and b + 8 share an XCD and its L2.  MODE 0 (round 1): member = blockIdx % G -- the G members of a
+// cloud sit on all 8 XCDs, every exchange crosses the fabric and the dependent load of the winner's
+// coordinates misses this XCD's L2 7 times out of 8.  MODE 1: the members of a cloud are blocks with
+// equal blockIdx % 8 (one XCD when G <= CUs/8), same agent-scope exchange.  MODE 2: as 1, plus each
+// cloud VERIFIES its placement once -- every member publishes its HW_REG_XCC_ID through the agent-scope
+// protocol (row 0 of the cloud's slots, unused otherwise) -- and when all members report one XCD the
+// per-iteration stores become workgroup-scope (written through the L1 into that XCD's L2, where the
+// pollers' L1-bypassing loads find them) instead of agent-scope write-through to memory.  Placement is
+// never assumed for correctness: an unverified cloud keeps the agent-scope protocol.
+//
+// Liveness.  All workgroups of the grid are resident by construction (grid <= CUs x occupancy of this
+// kernel, queried from the runtime) unless another kernel or a CU mask takes CUs away; so every spin is
+// bounded, a member whose wait times out flags ITS CLOUD in `timeout_flags` and abandons it, and the
+// host enqueues the single-workgroup kernel behind this one for exactly the flagged clouds.  Results are
+// therefore always the reference's; a timeout only costs time.
 // Measured and dropped: four self-validating 8-byte units per slot (key + three tagged coordinates)
 // so that the winner's coordinates arrive with its key instead of through the dependent load of
-// pts[last] at the top of the iteration -- 3.07 -> 3.71 ms at 16 x 131072 -> 1024: the extra
-// stores, the index-tracking reduction and the coordinate shuffles sit on the critical path and
-// cost more than the (L2-resident) load they remove.
+// pts[last] at the top of the iteration -- 3.07 -> 3.71 ms at 16 x 131072 -> 1024.
 // ---------------------------------------------------------------------------
-constexpr unsigned kFpsSpinLimit = 1u << 24;
+constexpr int kXcds = 8;
+
+__device__ __forceinline__ unsigned xcc_id() {
+  return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;  // HW_REG_XCC_ID[3:0]
+}
+
+// wave 0 of a member: wait until all G slots of `row` are non-zero, return their maximum (every lane);
+// 0 after `spin_limit` polls without success
+__device__ __forceinline__ unsigned long long fps_gather_row(const unsigned long long* __restrict__ row, int G,
+                                                             int lane, unsigned spin_limit) {
+  unsigned long long best = 0ull;
+  bool ok = true;
+  for (int base = 0; base < G && ok; base += kWave) {
+    const int m = base + lane;
+    unsigned long long mine = 1ull;
+    unsigned spins = 0;
+    for (;;) {
+      mine = m < G ? __hip_atomic_load(row + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1ull;
+      if (__all(mine != 0ull)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > spin_limit) {  // exit condition every wave reaches
+        ok = false;
+        break;
+      }
+    }
+    best = mine > best ? mine : best;
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), off, kWave);
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best, off, kWave);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    best = o > best ? o : best;
+  }
+  return ok ? best : 0ull;
+}
 
 template <int DT, int PPT>
 __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
     const float* __restrict__ points, const int64_t* __restrict__ lengths,
     const int64_t* __restrict__ Ks, const int64_t* __restrict__ start_idxs, int N, int P, int max_K,
-    int G, int n_clusters, unsigned long long* __restrict__ slots,
-    unsigned* __restrict__ timeout_flag, int64_t* __restrict__ idxs) {
+    int G, int n_clusters, int mode, unsigned spin_limit, unsigned long long* __restrict__ slots,
+    unsigned* __restrict__ timeout_flags, int64_t* __restrict__ idxs) {
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid / kWave;
-  const int cluster = blockIdx.x / G;
-  const int member = blockIdx.x - cluster * G;
+  int cluster, member;
+  if (mode == 0) {
+    cluster = blockIdx.x / G;
+    member = blockIdx.x - cluster * G;
+  } else {
+    // blocks with equal blockIdx % 8 share an XCD: deal each XCD's blocks to whole clusters
+    const int x = blockIdx.x % kXcds, j = blockIdx.x / kXcds;  // j-th block of XCD group x
+    cluster = (j / G) * kXcds + x;
+    member = j % G;
+  }
+  if (cluster >= n_clusters) return;  // (grid rounded up to a multiple of 8 * G)
   __shared__ float s_val[kFpsWaves];
   __shared__ int s_idx[kFpsWaves];
   __shared__ int s_last;
+  __shared__ int s_flag;
 
   for (int n = cluster; n < N; n += n_clusters) {
     int len = (int)lengths[n];
@@ -211,7 +271,29 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
     if (member == 0 && tid == 0) out[0] = last;
     unsigned long long* __restrict__ cslots = slots + (int64_t)n * max_K * G;
 
-    for (int k = 1; k < kn; ++k) {
+    // MODE 2: one verified-placement round per cloud (row 0): all members on one XCD?
+    bool same_xcd = false;
+    bool dead = false;  // this member's wait timed out: abandon the cloud (the repair pass redoes it)
+    if (G > 1 && mode == 2) {
+      if (wave == 0) {
+        const unsigned long long mine = 0x100ull | xcc_id();
+        if (lane == 0) __hip_atomic_store(cslots + member, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long mx = fps_gather_row(cslots, G, lane, spin_limit);
+        // all equal <=> max == every slot; re-read (they are final) and compare
+        bool eq = mx != 0ull;
+        for (int b2 = 0; b2 < G; b2 += kWave) {
+          const int m = b2 + lane;
+          const unsigned long long v = m < G ? __hip_atomic_load(cslots + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mx;
+          eq = eq && __all(v == mx);
+        }
+        if (lane == 0) s_flag = mx == 0ull ? -1 : (eq ? 1 : 0);
+      }
+      __syncthreads();
+      same_xcd = s_flag == 1;
+      dead = s_flag < 0;
+    }
+
+    for (int k = 1; k < kn && !dead; ++k) {
       float c[DT];
 #pragma unroll
       for (int d = 0; d < DT; ++d) c[d] = pts[(int64_t)last * DT + d];  // wave-uniform, read-only input
@@ -259,52 +341,35 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
         }
         int win = ix;  // valid in lane 0
         if (G > 1) {
-          // Exchange, whole wave 0: lane 0 publishes this member's key with ONE relaxed agent-scope
-          // store into its own slot of the (cloud, iteration) row -- the 8-byte key IS the message
-          // (distance bits << 32 | ~index, never 0), so no flag and no fence are needed; then the
-          // lanes poll the G slots of the row (one 128-byte line for G = 16) until all are non-zero
-          // and take the maximum: largest distance, lowest index on ties.
+          // Exchange, whole wave 0: lane 0 publishes this member's key with ONE store into its own slot
+          // of the (cloud, iteration) row -- the 8-byte key IS the message (distance bits << 32 | ~index,
+          // never 0) -- then the lanes poll the G slots of the row (one 128-byte line for G = 16)
+          // until all are non-zero and take the maximum: largest distance, lowest index on ties.
           unsigned long long* __restrict__ rowk = cslots + (int64_t)k * G;
           if (lane == 0) {
             const unsigned long long key =
                 (v >= 0.0f) ? (((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xffffffffu - (unsigned)ix))
                             : 1ull;  // this member holds no valid point (below every real key)
-            __hip_atomic_store(rowk + member, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (same_xcd) __hip_atomic_store(rowk + member, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(rowk + member, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          unsigned long long best = 0ull;
-          for (int base = 0; base < G; base += kWave) {
-            const int m = base + lane;
-            unsigned long long mine = 1ull;
-            unsigned spins = 0;
-            for (;;) {
-              mine = m < G ? __hip_atomic_load(rowk + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1ull;
-              if (__all(mine != 0ull)) break;
-              __builtin_amdgcn_s_sleep(1);
-              if (++spins > kFpsSpinLimit) {  // exit condition every wave reaches
-                if (lane == 0) __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-              }
-            }
-            best = mine > best ? mine : best;
+          const unsigned long long bestk = fps_gather_row(rowk, G, lane, spin_limit);
+          win = (int)(0xffffffffu - (unsigned)(bestk & 0xffffffffull));
+          if (bestk == 0ull) {
+            win = -1;
+            if (lane == 0) __hip_atomic_store(timeout_flags + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-#pragma unroll
-          for (int off = kWave / 2; off > 0; off >>= 1) {
-            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), off, kWave);
-            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best, off, kWave);
-            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-            best = o > best ? o : best;
-          }
-          win = (int)(0xffffffffu - (unsigned)(best & 0xffffffffull));
-          if (win < 0 || win >= len) win = 0;  // only reachable after a timeout
         }
         if (lane == 0) {
           s_last = win;
-          if (member == 0) out[k] = win;
+          if (member == 0 && win >= 0) out[k] = win;
         }
       }
       __syncthreads();
       last = s_last;
+      if (last < 0) dead = true;  // (workgroup-uniform)
     }
+    if (dead && tid == 0) __hip_atomic_store(timeout_flags + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();  // s_last / s_val reuse by the next cloud of this cluster
   }
 }
@@ -334,13 +399,29 @@ static void fps_plan(int64_t P, int* ppt, int* G) {
   *G = (int)ceil_div(P > 0 ? P : 1, (int64_t)p * kFpsBlock);
 }
 
+// workgroups of `kernel` the device can hold at once: CUs x the runtime's occupancy answer (the cluster
+// exchange needs every workgroup of the grid resident)
+template <class Kernel>
+static int fps_resident_blocks(Kernel kernel) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kFpsBlock, 0) != hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return fps_num_cus() * (per_cu > 1 ? 1 : per_cu);  // one 1024-lane workgroup per CU is what the plan uses
+}
+
+static size_t fps_slot_bytes(int64_t N, int64_t max_K, int G) {
+  return sizeof(unsigned long long) * (size_t)(N * max_K) * (size_t)(G > 1 ? G : 1);
+}
+
 extern "C" size_t pointops_fps_workspace_bytes(int64_t N, int64_t P, int64_t max_K) {
   // v1 running min-distance array (N*P floats) + v2 exchange rows: one u64 slot per
-  // (cloud, iteration, cluster member) + one timeout word
+  // (cloud, iteration, cluster member) + one timeout word per cloud
   int ppt, G;
   fps_plan(P, &ppt, &G);
   const size_t md = sizeof(float) * (size_t)(N * P);
-  const size_t ex = sizeof(unsigned long long) * (size_t)(N * max_K) * (size_t)(G > 1 ? G : 1) + 64;
+  const size_t ex = fps_slot_bytes(N, max_K, G) + sizeof(unsigned) * (size_t)N + 64;
   return ((md + 255) & ~(size_t)255) + ex;
 }
 
@@ -361,25 +442,49 @@ extern "C" int pointops_sample_farthest_points(const float* points, const int64_
   char* ex = (char*)workspace + ((sizeof(float) * (size_t)(N * P) + 255) & ~(size_t)255);
   int ppt, G;
   fps_plan(P, &ppt, &G);
-  const size_t slot_bytes = sizeof(unsigned long long) * (size_t)(N * max_K) * (size_t)(G > 1 ? G : 1);
+  const size_t slot_bytes = fps_slot_bytes(N, max_K, G);
   unsigned long long* slots = (unsigned long long*)ex;
-  unsigned* timeout_flag = (unsigned*)(ex + slot_bytes);
+  unsigned* timeout_flags = (unsigned*)(ex + slot_bytes);
 
+#define PO_LAUNCH(DT, FLAGS)                                                                      \
+  hipLaunchKernelGGL((fps_kernel<DT>), dim3((unsigned)N), dim3(kFpsBlock), 0, stream, points, lengths, K, \
+                     start_idxs, (int)P, (int)D, (int)max_K, idxs, min_dist_ws, FLAGS)
   // v2 (register-resident clusters) for D in {2,3}: up to PPT*1024 points per workgroup
-  const int cus = fps_num_cus();
   if ((D == 3 || D == 2) && P >= 1) {
-    if (G <= cus) {
-      int n_clusters = cus / G;
+    int resident = 0;
+#define PO_RES(DT, PPT) resident = fps_resident_blocks(fps_cluster_kernel<DT, PPT>)
+    if (D == 3) {
+      if (ppt == 4) PO_RES(3, 4);
+      else if (ppt == 8) PO_RES(3, 8);
+      else PO_RES(3, 16);
+    } else {
+      if (ppt == 4) PO_RES(2, 4);
+      else if (ppt == 8) PO_RES(2, 8);
+      else PO_RES(2, 16);
+    }
+#undef PO_RES
+    if (G <= resident) {
+      int mode = (int)debug_knob("fps_mode", 2);
+      const int per_xcd = resident / kXcds;  // blocks that share an XCD under round-robin dispatch
+      if (G > per_xcd || per_xcd < 1) mode = 0;  // a cloud does not fit one XCD: spread it (agent-scope exchange)
+      int n_clusters = mode == 0 ? resident / G : (per_xcd / G) * kXcds;
       if (n_clusters > N) n_clusters = (int)N;
       if (n_clusters < 1) n_clusters = 1;
-      if (G == 1) n_clusters = (int)N;  // no exchange: one independent workgroup per cloud
-      if (G > 1) {
-        if (hipMemsetAsync(ex, 0, slot_bytes + 64, stream) != hipSuccess) return check_launch("fps(memset)");
+      if (G == 1) {  // no exchange: one independent workgroup per cloud
+        n_clusters = (int)N;
+        mode = 0;
       }
-      const dim3 grid((unsigned)(n_clusters * G)), block(kFpsBlock);
+      if (G > 1) {
+        if (hipMemsetAsync(ex, 0, slot_bytes + sizeof(unsigned) * (size_t)N, stream) != hipSuccess)
+          return check_launch("fps(memset)");
+      }
+      // XCD-local numbering: cluster c = (j / G) * 8 + x for the j-th block of XCD group x
+      const int blocks = mode == 0 ? n_clusters * G : (int)ceil_div(n_clusters, kXcds) * G * kXcds;
+      const unsigned spin_limit = (unsigned)debug_knob("fps_spin_limit", 1 << 20);
+      const dim3 grid((unsigned)blocks), block(kFpsBlock);
 #define PO_LAUNCH_C(DT, PPT)                                                                         \
   hipLaunchKernelGGL((fps_cluster_kernel<DT, PPT>), grid, block, 0, stream, points, lengths, K, start_idxs, \
-                     (int)N, (int)P, (int)max_K, G, n_clusters, slots, timeout_flag, idxs)
+                     (int)N, (int)P, (int)max_K, G, n_clusters, mode, spin_limit, slots, timeout_flags, idxs)
       if (D == 3) {
         if (ppt == 4) PO_LAUNCH_C(3, 4);
         else if (ppt == 8) PO_LAUNCH_C(3, 8);
@@ -390,17 +495,19 @@ extern "C" int pointops_sample_farthest_points(const float* points, const int64_
         else PO_LAUNCH_C(2, 16);
       }
 #undef PO_LAUNCH_C
-      return check_launch("sample_farthest_points");
+      int rc = check_launch("sample_farthest_points");
+      if (rc != POINTOPS_OK || G == 1) return rc;
+      // repair pass: clouds whose exchange timed out (CUs taken away by another kernel or a CU mask) are
+      // redone by the single-workgroup kernel; a cloud that was not flagged returns at once
+      if (D == 3) PO_LAUNCH(3, (const unsigned*)timeout_flags);
+      else PO_LAUNCH(2, (const unsigned*)timeout_flags);
+      return check_launch("sample_farthest_points(repair)");
     }
   }
-  const dim3 grid((unsigned)N), block(kFpsBlock);
-#define PO_LAUNCH(DT)                                                                             \
-  hipLaunchKernelGGL((fps_kernel<DT>), grid, block, 0, stream, points, lengths, K, start_idxs,     \
-                     (int)P, (int)D, (int)max_K, idxs, min_dist_ws)
   switch (D) {
-    case 2: PO_LAUNCH(2); break;
-    case 3: PO_LAUNCH(3); break;
-    default: PO_LAUNCH(0); break;
+    case 2: PO_LAUNCH(2, nullptr); break;
+    case 3: PO_LAUNCH(3, nullptr); break;
+    default: PO_LAUNCH(0, nullptr); break;
   }
 #undef PO_LAUNCH
   return check_launch("sample_farthest_points");

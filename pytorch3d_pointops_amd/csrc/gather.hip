@@ -157,7 +157,7 @@ extern "C" int pointops_gather_neighbors_backward(const float* grad_out, const i
   POINTOPS_REQUIRE(N >= 0 && M >= 0 && U >= 1 && L >= 0 && K >= 0 && U < (1LL << 31) && K < (1LL << 31),
                    "gather_neighbors_backward: bad sizes");
   hipStream_t stream = (hipStream_t)stream_;
-  const TiledPlan plan = tiled_plan(N, L, K, M, (int)U, "POINTOPS_GATHER_BWD_MODE", "POINTOPS_GATHER_BWD_SPLIT");
+  const TiledPlan plan = tiled_plan(N, L, K, M, (int)U, "gather_bwd_mode", "gather_bwd_split");
   if (N * M * U > 0 && !(plan.tiled && plan.S == 1)) {
     if (hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)(N * M * U), stream) != hipSuccess)
       return check_launch("gather_neighbors_backward(memset)");

@@ -23,6 +23,7 @@
 //   * grid = clouds x ceil(P1/256) workgroups of 256 lanes (>> 256 CUs at the
 //     bench sizes); all workgroups of a cloud re-stream the same 12*P2 bytes,
 //     which stay L2/Infinity-Cache resident (786 KB per cloud at P2=65536).
+#include "debug.h"
 #include "knn_common.h"
 
 #include <algorithm>
@@ -336,7 +337,7 @@ int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* len
     }
     const int rc = knn_grid_run(a, norm, workspace);
     if (rc != POINTOPS_OK) return rc;
-  } else if (v == 0 && knn_wide_supported(D, K) && !getenv("POINTOPS_KNN_GENERIC")) {
+  } else if (v == 0 && knn_wide_supported(D, K) && debug_knob("knn_generic", 0) == 0) {
     // any D / long lists: LDS-transposed queries (POINTOPS_KNN_GENERIC=1 keeps the plain fallback, tests)
     const size_t need = knn_split_workspace_bytes(N, P1, P2, K);
     if (need > 0 && (workspace == nullptr || workspace_bytes < need)) {

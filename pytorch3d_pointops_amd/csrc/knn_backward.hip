@@ -258,7 +258,7 @@ extern "C" int pointops_knn_points_backward(const float* p1, const float* p2,
                    "knn_points_backward: sizes must fit int32");
   hipStream_t stream = (hipStream_t)stream_;
   // grad_p2 mode: LDS tiles when the neighbour table is large and p2 splits into few tiles
-  const TiledPlan plan = tiled_plan(N, P1, K, P2, (int)D, "POINTOPS_KNN_BWD_MODE", "POINTOPS_KNN_BWD_SPLIT");
+  const TiledPlan plan = tiled_plan(N, P1, K, P2, (int)D, "knn_bwd_mode", "knn_bwd_split");
   const bool tiled = plan.tiled;
   const int S = plan.S;
   if (N * P2 * D > 0 && !(tiled && S == 1)) {

@@ -1,0 +1,11 @@
+// knn_grid_d2.hip -- instantiates the grid search kernels (knn_grid_search.h) for D = 2.
+#include "knn_grid_search.h"
+
+namespace pointops {
+
+void grid_search_d2(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool quad) {
+  if (norm == 1) grid_search_dispatch<2, 1>(a, ws, kc, quad);
+  else grid_search_dispatch<2, 2>(a, ws, kc, quad);
+}
+
+}  // namespace pointops

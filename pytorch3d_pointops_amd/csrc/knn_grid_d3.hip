@@ -1,0 +1,11 @@
+// knn_grid_d3.hip -- instantiates the grid search kernels (knn_grid_search.h) for D = 3.
+#include "knn_grid_search.h"
+
+namespace pointops {
+
+void grid_search_d3(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool quad) {
+  if (norm == 1) grid_search_dispatch<3, 1>(a, ws, kc, quad);
+  else grid_search_dispatch<3, 2>(a, ws, kc, quad);
+}
+
+}  // namespace pointops

@@ -1,0 +1,679 @@
+// knn_grid_search.h -- search kernels of the exact grid-pruned KNN (gfx950); the algorithm, the
+// exactness argument and the pass list are in knn_grid.hip.  Templates only: the translation units
+// knn_grid_d*.hip instantiate them per point dimension so that they compile in parallel.
+#pragma once
+#include "grid.h"
+#include "knn_common.h"
+#include "sort_net.h"
+
+#include <type_traits>
+
+namespace pointops {
+
+// Write one output row from a TopKF64 list: the first min(K, len2) entries, zeros after (knn_cpu.cpp:25-26).
+template <int KC>
+__device__ __forceinline__ void write_row_f64(const TopKF64<KC>& top, int K, int len2, int64_t* __restrict__ orow_i,
+                                              float* __restrict__ orow_d) {
+  const int kvalid = len2 < K ? len2 : K;
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    if (k < K) {
+      const bool ok = k < kvalid;
+      orow_i[k] = ok ? (int64_t)top.idx_at(k) : 0;
+      orow_d[k] = ok ? top.dist_at(k) : 0.0f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 5 (lane-private search): one query per lane, EVERY lane walks only the 3x3x3 cell cube
+// around its own cell -- up to 9 contiguous runs of the cell-sorted records (a row of three
+// x-cells is contiguous).  The queries are processed in cell order, so the 64 lanes of a wave sit
+// in ~10 neighbouring cells and their runs overlap in L1/L2.
+//
+// Walk.  A lane consumes its runs in GROUPS of G consecutive records: one 32-bit byte offset per
+// group, the G gathers are `global_load_dwordx4 v, v_off, s[base] offset:16u` (no per-record address
+// arithmetic), a record's registers are reloaded with the NEXT group's record as soon as its distance
+// is taken (in-place software pipeline).  A group never straddles two runs: the tail of a run's last
+// group lies beyond the run (real records of other cells, or the pad behind the cloud) and is masked
+// by ONE compare per record (`16u < remaining bytes`).  Moving to the next run is per lane, under an
+// exec mask, from a per-lane list of the NON-EMPTY runs in LDS.  (Round 1 let groups straddle runs with
+// per-record selects: ~26 VALU per record, a third of them v_cndmask_b32 on a shared VCC, which costs
+// ~22 cycles for every consumer after the first -- tools/valu_microbench.hip.  Now ~11.)
+//
+// Selection.  KC >= 8: candidates that beat the lane's (stale) threshold are parked in a per-lane LDS
+// queue; when ANY lane's queue is nearly full all lanes merge queue and list with branch-free sorting
+// networks on 64-bit (dist, idx) keys driven through the FP64 pipe (sort_net.h: a compare-exchange is
+// v_min_f64 + v_max_f64).  Queue slots are re-filled with the empty key after a flush, so reading the
+// queue needs no per-slot validity select.  KC <= 4: branch-free sorted insert (2 KC - 1 FP64 min/max)
+// under the exec mask of the lanes whose candidate passes.
+//
+// The certification bound is known before the walk and seeds the threshold (seed_threshold()).
+// ---------------------------------------------------------------------------
+constexpr int kLaneRows = 9;
+
+template <int KC>
+struct LaneCfg {
+  static constexpr bool kUseQueue = KC >= 8;
+  static constexpr int kQueueCap = 16;                  // per-lane LDS queue slots (KC = 8 merges the 8 smallest)
+  static constexpr int kGroup = KC >= 8 ? 8 : 4;        // records per group
+  static constexpr int kSub = kGroup;                   // candidates between two queue-full checks (whole groups:
+                                                        // a check inside the group needs two code paths that merge, and
+                                                        // the compiler then rotates the record registers with copies
+                                                        // behind an s_waitcnt vmcnt(0))
+};
+
+template <int D, int KC, int NORM>
+__global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
+    const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const int* __restrict__ chunk_prefix,
+    const float* __restrict__ edges, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
+    const int* __restrict__ qlist, int* __restrict__ fb_count, int* __restrict__ fb_list,
+    unsigned* __restrict__ fb_kth, int cell_cap, int P1, int P2, int K, int N, int64_t* __restrict__ idxs,
+    float* __restrict__ dists) {
+  using Cfg = LaneCfg<KC>;
+  constexpr bool kUseQueue = Cfg::kUseQueue;
+  constexpr int kQueueCap = Cfg::kQueueCap;
+  constexpr int kSub = Cfg::kSub;
+  constexpr int G = Cfg::kGroup;
+  constexpr int kGroupBytes = G * 16;
+  static_assert(G % kSub == 0 && G <= kSortedPad, "group geometry");
+  __shared__ double s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
+  __shared__ int2 s_rows[kLaneRows + 1][kGridWave];  // per-lane (first record, end) of its non-empty runs, then (0, 0)
+
+  const int lane = threadIdx.x;
+  const int total = chunk_prefix[N];
+  if (kUseQueue) {
+#pragma unroll
+    for (int t = 0; t < kQueueCap; ++t) s_queue[t * kGridWave + lane] = TopKF64<KC>::empty();
+  }
+  double* const qbase = s_queue + lane;
+  int2* const rows = &s_rows[0][0];
+  // XCD-aware item order: workgroup b runs on XCD b % 8 (round-robin dispatch), and the chunks are
+  // sorted by (cloud, cell).  Each XCD walks its own contiguous eighth of the chunk list, so the
+  // ~1000 chunks it has in flight belong to one or two clouds whose sorted records (1 MB at 65536
+  // points) stay in that XCD's 4 MB L2, instead of every XCD touching every cloud in flight.
+  const int xcd = blockIdx.x % kNumXcd, per_xcd = (total + kNumXcd - 1) / kNumXcd;
+  for (int j = blockIdx.x / kNumXcd; j < per_xcd; j += gridDim.x / kNumXcd) {
+    const int item = xcd * per_xcd + j;
+    if (item >= total) break;
+    const int n = item_cloud(chunk_prefix, N, item);
+    const GridCloud g = clouds[n];
+    const int c0 = (item - chunk_prefix[n]) * kGridWave;
+    const bool active = c0 + lane < g.len1;
+    const float4* __restrict__ sp = sorted + (int64_t)n * (P2 + kSortedPad);
+    int qi = 0;
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (g.same) {  // the queries are the points: the cell-sorted records are the query order (coalesced)
+      if (active) {
+        const float4 q = sp[c0 + lane];
+        qx = q.x;
+        qy = q.y;
+        qz = q.z;
+        qi = __float_as_int(q.w);
+      }
+    } else if (active) {
+      qi = qlist[(int64_t)n * P1 + c0 + lane];
+      load_point3<D>(p1 + ((int64_t)n * P1 + qi) * D, qx, qy, qz);
+    }
+    int cx, cy, cz;
+    point_cells(g, qx, qy, qz, cx, cy, cz);
+    const int X0 = max(cx - 1, 0), X1 = min(cx + 1, g.G[0] - 1);
+    const int Y0 = max(cy - 1, 0), Y1 = min(cy + 1, g.G[1] - 1);
+    const int Z0 = max(cz - 1, 0), Z1 = min(cz + 1, g.G[2] - 1);
+    const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
+
+    // rigorous lower bound of every point outside the lane's cube (certification), known before the
+    // walk: it also seeds the candidate threshold
+    bool whole;
+    const float lb = box_lower_bound<NORM>(g, edges + (int64_t)n * 3 * kEdgeStride, qx, qy, qz, X0, X1, Y0, Y1, Z0,
+                                           Z1, whole);
+    const unsigned thr0 = seed_threshold(lb, whole);
+
+    // the lane's non-empty runs, own row first (near-first order tightens the thresholds early)
+    {
+      int cnt = 0;  // rows written so far, as an element offset into s_rows
+#pragma unroll
+      for (int r = 0; r < kLaneRows; ++r) {
+        constexpr int kDz[kLaneRows] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+        constexpr int kDy[kLaneRows] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+        const int z = cz + kDz[r], y = cy + kDy[r];
+        if (active && z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1]) {
+          const int rowbase = (z * g.G[1] + y) * g.G[0];
+          const int s = cstart[rowbase + X0], e = cstart[rowbase + X1 + 1];
+          if (e > s) {
+            rows[lane + cnt] = make_int2(s, e);
+            cnt += kGridWave;
+          }
+        }
+      }
+      // terminators: every slot from the lane's count on (a finished lane keeps reading (0, 0))
+#pragma unroll
+      for (int r = 0; r <= kLaneRows; ++r) {
+        if (r * kGridWave >= cnt) s_rows[r][lane] = make_int2(0, 0);
+      }
+    }
+    int rowi = lane + 2 * kGridWave;  // entry of `rows` after the prefetched one
+    const int rowlast = lane + kLaneRows * kGridWave;
+    unsigned off;  // byte offset of the lane's next group inside the cloud's record array
+    int rem;       // bytes of the current run from `off` on (<= 0: the run is used up)
+    int2 nse;      // the lane's next run, read from LDS one switch ahead (its latency stays off the walk)
+    {
+      const int2 se = rows[lane];
+      off = (unsigned)se.x * 16u;
+      rem = (se.y - se.x) * 16;
+      nse = rows[lane + kGridWave];
+    }
+    auto advance = [&]() __attribute__((always_inline)) {
+      rem -= kGroupBytes;
+      off += kGroupBytes;
+      if (rem <= 0) {  // next run of this lane (exec-masked; some lane switches in most iterations)
+        off = (unsigned)nse.x * 16u;
+        rem = (nse.y - nse.x) * 16;
+        nse = rows[rowi];
+        rowi = min(rowi + kGridWave, rowlast);
+      }
+    };
+    const char* __restrict__ spb = (const char*)sp;
+    auto record = [&](unsigned o, int u) __attribute__((always_inline)) -> float4 {
+      return *(const float4*)(spb + o + (unsigned)(16 * u));  // saddr + 32-bit voffset + immediate
+    };
+
+    TopKF64<KC> top;
+    top.init();
+    unsigned thr = thr0;
+    int qn = lane;  // next free slot of the lane's queue (element index into s_queue)
+
+    float4 c[G];
+    int crem = rem;  // validity of the group held in c[]: record u is part of the run iff 16 u < crem
+#pragma unroll
+    for (int u = 0; u < G; ++u) c[u] = record(off, u);
+    // kSub records of the group in c[], starting at u0 (compile-time): distances, then reload the registers
+    // with the NEXT group's records, then the threshold tests
+    auto part = [&](auto u0c) __attribute__((always_inline)) {
+      constexpr int u0 = decltype(u0c)::value;
+      float dd[kSub];
+      int ii[kSub];
+#pragma unroll
+      for (int u = u0; u < u0 + kSub; ++u) {
+        dd[u - u0] = point_dist<D, NORM>(qx, qy, qz, c[u]);
+        ii[u - u0] = __float_as_int(c[u].w);
+      }
+      // the reloads stay BEHIND the distances (hoisted above them, old and new records overlap in lifetime
+      // and the compiler copies four float4 per part to rotate the registers)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = u0; u < u0 + kSub; ++u) c[u] = record(off, u);  // next group's records into the same registers
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < kSub; ++t) {
+        const bool valid = 16 * (u0 + t) < crem;
+        if (kUseQueue) {
+          if (valid && __float_as_uint(dd[t]) <= thr) {
+            s_queue[qn] = TopKF64<KC>::make(dd[t], ii[t]);
+            qn += kGridWave;
+          }
+        } else if (valid && __float_as_uint(dd[t]) <= min(top.worst_bits(), thr0)) {
+          top.insert(TopKF64<KC>::make(dd[t], ii[t]));
+        }
+      }
+    };
+    if constexpr (kUseQueue) {
+      // The sorted list lives in 2 KC registers that only a flush touches: the walk is an INNER loop that
+      // never names them (a flush inside the walk loop made the compiler shuffle the whole list between
+      // two register sets on every iteration), left whenever some lane's queue could overflow in the next group.
+      static_assert(G == kSub && kQueueCap >= 2 * kSub, "queue geometry");
+      bool more = __any(crem > 0);
+      while (more) {
+        bool full;
+        do {
+          advance();  // (off, rem) now describe the NEXT group
+          part(std::integral_constant<int, 0>{});
+          crem = rem;
+          more = __any(crem > 0);
+          full = __any(qn > lane + (kQueueCap - kSub) * kGridWave);
+        } while (!full && more);
+        // merge: queue -> sorted network -> list
+        double qk[kQueueCap];
+#pragma unroll
+        for (int t = 0; t < kQueueCap; ++t) qk[t] = qbase[t * kGridWave];  // free slots hold the empty key
+#pragma unroll
+        for (int t = 0; t < kQueueCap; ++t) qbase[t * kGridWave] = TopKF64<KC>::empty();
+        bitonic_sort<kQueueCap>(qk);
+        constexpr int kMeet = KC < kQueueCap ? KC : kQueueCap;
+#pragma unroll
+        for (int t = 0; t < kMeet; ++t) top.key[KC - 1 - t] = kmin(top.key[KC - 1 - t], qk[t]);  // list slot KC-1-t meets queue entry t
+        bitonic_merge<KC>(top.key);
+        qn = lane;
+        thr = min(top.worst_bits(), thr0);
+      }
+    } else {
+      static_assert(G == kSub, "direct-insert variants take one part per group");
+      while (__any(crem > 0)) {
+        advance();
+        part(std::integral_constant<int, 0>{});
+        crem = rem;
+      }
+    }
+
+    const unsigned kth_bits = top.kth_bits(K);  // the K-th best, not the list's last slot
+    const bool full = kth_bits < 0x7f800000u;
+    const bool ok = whole || (full && __uint_as_float(kth_bits) < lb);
+    if (active) {
+      if (ok) {
+        const int64_t row = (int64_t)n * P1 + qi;
+        write_row_f64<KC>(top, K, g.len2, idxs + row * K, dists + row * K);
+      } else {
+        const int pos = atomicAdd(fb_count + n, 1);
+        fb_list[(int64_t)n * P1 + pos] = qi;
+        // The seeded threshold admitted only the m < KC candidates below lb, so the KC-th best itself is
+        // unknown; hand the quad pass an ESTIMATE from the density they imply (m points inside radius
+        // sqrt(lb) -> K points inside sqrt(lb) (K/m)^(1/3)), 30 % up.  It only picks the cube to search.
+        int m = 0;
+#pragma unroll
+        for (int t = 0; t < KC; ++t) m += (unsigned)__double2hiint(top.key[t]) < 0x7f800000u ? 1 : 0;
+        const float est = m > 0 ? lb * __powf(fmaxf((float)K / (float)m, 1.0f), NORM == 1 ? 0.33333f : 0.66667f) * 1.3f
+                                : __builtin_inff();
+        fb_kth[(int64_t)n * P1 + pos] = __float_as_uint(est);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 5b: radius-2 search for the queries pass 5 could not certify (~1 % of a cloud).
+// FOUR lanes share a query: the 25 (y, z) rows of the 5x5x5 cell cube around the query's
+// cell are dealt round-robin (nearest rows first) to the quad's lanes, each lane walks its
+// <= 7 contiguous runs (per-lane 16-byte gathers, eight in flight per pipeline stage, stale-threshold
+// queue, sorting-network merges), and two quad-permute exchange steps merge the four sorted lists,
+// after which every lane of the quad holds the cube's KC best.  (Kernel time at cfg2 with 4 / 8 / 16
+// lanes per query: 83 / 96 / 97-107 us -- the pass is throughput-bound, not bound by one wave's chain,
+// so fewer, longer lanes win.)  The cube grows from 3x3x3 only past the faces that an ESTIMATE of the
+// KC-th distance reaches.  The same rigorous face bound decides; what is still uncertified (far-away
+// queries) goes to the expanding wave search.
+// ---------------------------------------------------------------------------
+constexpr int kQuadLanes = 4;  // lanes per query
+constexpr int kQuadRows = (25 + kQuadLanes - 1) / kQuadLanes;
+constexpr int kQuadQueries = kGridWave / kQuadLanes;
+constexpr int kQuadFetch = 8;  // gathers in flight per lane and pipeline stage
+__device__ constexpr signed char kQuadDy[32] = {0, 0, 0, -1, 1, -1, -1, 1, 1, 0, 0, -2, 2, -1, 1, -1, 1, -2, -2, 2, 2, -2, -2, 2, 2, 0, 0, 0, 0, 0, 0, 0};
+__device__ constexpr signed char kQuadDz[32] = {0, -1, 1, 0, 0, -1, 1, -1, 1, -2, 2, 0, 0, -2, -2, 2, 2, -1, 1, -1, 1, -2, 2, -2, 2, 0, 0, 0, 0, 0, 0, 0};
+
+// DPP controls: quad_perm [1,0,3,2] (lane ^ 1), quad_perm [2,3,0,1] (lane ^ 2)
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E;
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// merge the partner lane's ascending list into mine: both lanes end with the KC smallest of the union
+template <int KC, int CTRL>
+__device__ __forceinline__ void dpp_merge(TopKF64<KC>& top) {
+  double o[KC];
+#pragma unroll
+  for (int t = 0; t < KC; ++t) o[t] = dpp_f64<CTRL>(top.key[t]);
+  if constexpr (KC >= 2) {
+#pragma unroll
+    for (int t = 0; t < KC; ++t) top.key[t] = kmin(top.key[t], o[KC - 1 - t]);  // bitonic, holds the KC smallest
+    bitonic_merge<KC>(top.key);
+  } else {
+    top.key[0] = kmin(top.key[0], o[0]);
+  }
+}
+
+template <int D, int KC, int NORM>
+__global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
+    const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const float* __restrict__ edges,
+    const int* __restrict__ cell_start, const float4* __restrict__ sorted, const int* __restrict__ fb_count,
+    const int* __restrict__ fb_list, const unsigned* __restrict__ fb_kth, int* __restrict__ fb3_count,
+    int* __restrict__ fb3_list, int cell_cap, int P1, int P2, int K, int64_t* __restrict__ idxs,
+    float* __restrict__ dists) {
+  constexpr bool kUseQueue = KC >= 8;
+  constexpr int kQueueCap = KC < 16 ? KC : 16;
+  constexpr int kSub = 4;
+  static_assert(kQuadFetch % kSub == 0, "fetch groups are processed four candidates at a time");
+  __shared__ double s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
+  __shared__ int2 s_rows[kQuadRows][kGridWave];
+
+  const int n = blockIdx.y;
+  const int cnt = fb_count[n];
+  const int lane = threadIdx.x;
+  const int sub = lane & (kQuadLanes - 1);
+  const GridCloud g = clouds[n];
+  const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
+  const float4* __restrict__ sp = sorted + (int64_t)n * (P2 + kSortedPad);  // record P2: the cloud's NaN sentinel
+  const float* __restrict__ ed = edges + (int64_t)n * 3 * kEdgeStride;
+  double* const qbase = s_queue + lane;
+  if (kUseQueue) {
+#pragma unroll
+    for (int t = 0; t < kQueueCap; ++t) qbase[t * kGridWave] = TopKF64<KC>::empty();
+  }
+
+  for (int base = blockIdx.x * kQuadQueries; base < cnt; base += gridDim.x * kQuadQueries) {
+    const int w = base + lane / kQuadLanes;
+    const bool active = w < cnt;
+    const int qi = active ? fb_list[(int64_t)n * P1 + w] : 0;
+    float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+    if (active) load_point3<D>(p1 + ((int64_t)n * P1 + qi) * D, qx, qy, qz);
+    int cx, cy, cz;
+    point_cells(g, qx, qy, qz, cx, cy, cz);
+    // The cube grows by one cell only past the faces of the 3x3x3 cube that the lane search's KC-th best
+    // reached (a superset search can only lower it, so the other faces stay certified): typically one
+    // face -> 36 cells instead of 125.  Whatever cube is searched is certified against ITS faces below.
+    const float kth3 = __uint_as_float(active ? fb_kth[(int64_t)n * P1 + w] : 0x7f800000u);
+    auto reach = [&](bool has, float bound) { return (has && !(kth3 < bound)) ? 2 : 1; };
+    const int ex0 = reach(cx - 1 > 0, face_bound<NORM>(qx - prev_float(ed[max(cx - 1, 0)])));
+    const int ex1 = reach(cx + 1 < g.G[0] - 1, face_bound<NORM>(ed[min(cx + 2, g.G[0])] - qx));
+    const int ey0 = reach(cy - 1 > 0, face_bound<NORM>(qy - prev_float(ed[kEdgeStride + max(cy - 1, 0)])));
+    const int ey1 = reach(cy + 1 < g.G[1] - 1, face_bound<NORM>(ed[kEdgeStride + min(cy + 2, g.G[1])] - qy));
+    const int ez0 = reach(cz - 1 > 0, face_bound<NORM>(qz - prev_float(ed[2 * kEdgeStride + max(cz - 1, 0)])));
+    const int ez1 = reach(cz + 1 < g.G[2] - 1, face_bound<NORM>(ed[2 * kEdgeStride + min(cz + 2, g.G[2])] - qz));
+    const int X0 = max(cx - ex0, 0), X1 = min(cx + ex1, g.G[0] - 1);
+    const int Y0 = max(cy - ey0, 0), Y1 = min(cy + ey1, g.G[1] - 1);
+    const int Z0 = max(cz - ez0, 0), Z1 = min(cz + ez1, g.G[2] - 1);
+    bool whole;
+    const float lb = box_lower_bound<NORM>(g, ed, qx, qy, qz, X0, X1, Y0, Y1, Z0, Z1, whole);
+    const unsigned thr0 = seed_threshold(lb, whole);
+
+#pragma unroll
+    for (int j = 0; j < kQuadRows; ++j) {
+      const int rr = sub + kQuadLanes * j;  // table entries >= 25 do not exist
+      const int z = cz + kQuadDz[rr], y = cy + kQuadDy[rr];
+      int2 se = make_int2(0, 0);
+      if (active && rr < 25 && z >= Z0 && z <= Z1 && y >= Y0 && y <= Y1) {
+        const int rowbase = (z * g.G[1] + y) * g.G[0];
+        se.x = cstart[rowbase + X0];
+        se.y = cstart[rowbase + X1 + 1];
+      }
+      s_rows[j][lane] = se;
+    }
+    int r = 0;
+    int cur = s_rows[0][lane].x, end = s_rows[0][lane].y;
+    auto next_record = [&]() -> int {
+      while (cur >= end && r < kQuadRows - 1) {
+        ++r;
+        const int2 se = s_rows[r][lane];
+        cur = se.x;
+        end = se.y;
+      }
+      return cur < end ? cur++ : P2;  // exhausted: the NaN sentinel record
+    };
+
+    TopKF64<KC> top;
+    top.init();
+    unsigned thr = thr0;
+    int qn = lane;
+    auto flush = [&]() {
+      double qk[kQueueCap];
+#pragma unroll
+      for (int t = 0; t < kQueueCap; ++t) qk[t] = qbase[t * kGridWave];
+#pragma unroll
+      for (int t = 0; t < kQueueCap; ++t) qbase[t * kGridWave] = TopKF64<KC>::empty();
+      bitonic_sort<kQueueCap>(qk);
+#pragma unroll
+      for (int t = 0; t < kQueueCap; ++t) top.key[KC - 1 - t] = kmin(top.key[KC - 1 - t], qk[t]);
+      bitonic_merge<KC>(top.key);
+      qn = lane;
+      thr = min(top.worst_bits(), thr0);
+    };
+    auto fetch = [&](float4 (&c)[kQuadFetch]) -> bool {
+      int a[kQuadFetch];
+#pragma unroll
+      for (int u = 0; u < kQuadFetch; ++u) a[u] = next_record();
+#pragma unroll
+      for (int u = 0; u < kQuadFetch; ++u) c[u] = sp[a[u]];  // unconditional: exhausted lanes read the sentinel
+      return a[0] != P2;
+    };
+    float4 c[kQuadFetch];
+    bool more = fetch(c);
+    while (__any(more)) {
+      float4 nxt[kQuadFetch];
+      const bool more_next = fetch(nxt);
+#pragma unroll
+      for (int u0 = 0; u0 < kQuadFetch; u0 += kSub) {
+#pragma unroll
+        for (int u = u0; u < u0 + kSub; ++u) {
+          const float d = point_dist<D, NORM>(qx, qy, qz, c[u]);  // sentinel: NaN, above every threshold
+          if (kUseQueue) {
+            if (__float_as_uint(d) <= thr) {
+              s_queue[qn] = TopKF64<KC>::make(d, __float_as_int(c[u].w));
+              qn += kGridWave;
+            }
+          } else if (__float_as_uint(d) <= min(top.worst_bits(), thr0)) {
+            top.insert(TopKF64<KC>::make(d, __float_as_int(c[u].w)));
+          }
+        }
+        if (kUseQueue) {
+          if (__any(qn > lane + (kQueueCap - kSub) * kGridWave)) flush();
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kQuadFetch; ++u) c[u] = nxt[u];
+      more = more_next;
+    }
+    if (kUseQueue) flush();
+
+    // the group's sorted lists -> one, held by every lane of the group
+    dpp_merge<KC, kDppXor1>(top);
+    dpp_merge<KC, kDppXor2>(top);
+
+    const unsigned kth_bits = top.kth_bits(K);  // the K-th best, not the list's last slot
+    const bool full = kth_bits < 0x7f800000u;
+    const bool ok = whole || (full && __uint_as_float(kth_bits) < lb);
+    if (active && sub == 0) {
+      if (ok) {
+        const int64_t row = (int64_t)n * P1 + qi;
+        write_row_f64<KC>(top, K, g.len2, idxs + row * K, dists + row * K);
+      } else {
+        const int pos = atomicAdd(fb3_count + n, 1);
+        fb3_list[(int64_t)n * P1 + pos] = qi;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass 6: wave-per-query EXPANDING search for the queries the lane / quad passes could not certify
+// (typically < 0.1 % of a cloud).  The wave's 64 lanes split the candidate records of
+// the cube of cells [c - r, c + r]^3 around the query's cell (coalesced 16-byte
+// loads along each row's contiguous run), keep a private lexicographic top-K each,
+// and K rounds of a wave-wide 64-bit min extract the K global minima.  The same
+// rigorous face bound decides; on failure r doubles, until the cube is the whole
+// grid (always exact) or more than kWaveRegionCap records were scanned, in which
+// case the query goes to the whole-cloud lane-per-query scan (far-away queries).
+// ---------------------------------------------------------------------------
+constexpr int kWaveKernelBlock = 256;
+constexpr int kWaveKernelWgsPerCloud = 64;
+constexpr int kWaveRegionCap = 16384;
+constexpr int kWaveRows = 96;  // (2r+1)^2 rows for r = 2 (25) and r = 4 (81)
+
+template <int D, int KC, int NORM>
+__global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
+    const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const float* __restrict__ edges,
+    const int* __restrict__ cell_start, const float4* __restrict__ sorted, const int* __restrict__ fb_count,
+    const int* __restrict__ fb_list, int* __restrict__ fb2_count, int* __restrict__ fb2_list, int cell_cap,
+    int P1, int P2, int K, int r_start, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+  __shared__ int s_rowsrc[kWaveKernelBlock / kWave][kWaveRows];
+  __shared__ int s_rowoff[kWaveKernelBlock / kWave][kWaveRows + 1];
+  const int n = blockIdx.y;
+  const int cnt = fb_count[n];
+  if (cnt == 0) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wslot = threadIdx.x / kWave;
+  const int wave = blockIdx.x * (kWaveKernelBlock / kWave) + threadIdx.x / kWave;
+  constexpr int kWavesPerCloud = kWaveKernelWgsPerCloud * (kWaveKernelBlock / kWave);
+  const GridCloud g = clouds[n];
+  const float* __restrict__ ed = edges + (int64_t)n * 3 * kEdgeStride;
+  const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
+  const float4* __restrict__ sp = sorted + (int64_t)n * (P2 + kSortedPad);
+  const int kvalid = g.len2 < K ? g.len2 : K;
+
+  for (int w = wave; w < cnt; w += kWavesPerCloud) {
+    const int qi = fb_list[(int64_t)n * P1 + w];  // wave-uniform
+    const int64_t row = (int64_t)n * P1 + qi;
+    float qx, qy, qz;
+    load_point3<D>(p1 + row * D, qx, qy, qz);
+    int cx, cy, cz;
+    point_cells(g, qx, qy, qz, cx, cy, cz);
+    bool done = false;
+    for (int r = r_start; !done; r *= 2) {
+      const int X0 = max(cx - r, 0), X1 = min(cx + r, g.G[0] - 1);
+      const int Y0 = max(cy - r, 0), Y1 = min(cy + r, g.G[1] - 1);
+      const int Z0 = max(cz - r, 0), Z1 = min(cz + r, g.G[2] - 1);
+      bool whole;
+      const float lb = box_lower_bound<NORM>(g, ed, qx, qy, qz, X0, X1, Y0, Y1, Z0, Z1, whole);
+      TopKF64<KC> top;
+      top.init();
+      auto consider = [&](const float4 c) {
+        const float d = point_dist<D, NORM>(qx, qy, qz, c);
+        if (__float_as_uint(d) <= top.worst_bits()) top.insert(TopKF64<KC>::make(d, __float_as_int(c.w)));
+      };
+      int scanned = 0;
+      bool giveup = false;
+      const int ny = Y1 - Y0 + 1, nrows = ny * (Z1 - Z0 + 1);
+      if (nrows <= kWaveRows) {
+        // Small cubes (r = 2, 4): latency-bound if walked row by row (two dependent scalar loads
+        // per row, then one load per lane).  Instead the lanes fetch all row bounds at once,
+        // a wave scan turns them into a flat record stream, and every lane then owns the
+        // records lane, lane+64, ... with four loads in flight.
+        int* __restrict__ rs = s_rowsrc[wslot];
+        int* __restrict__ ro = s_rowoff[wslot];
+        for (int r0 = 0; r0 < nrows; r0 += kWave) {
+          const int rr = r0 + lane;
+          int len_r = 0, src = 0;
+          if (rr < nrows) {
+            const int z = Z0 + rr / ny, y = Y0 + rr % ny;
+            const int rowbase = (z * g.G[1] + y) * g.G[0];
+            src = cstart[rowbase + X0];
+            len_r = cstart[rowbase + X1 + 1] - src;
+          }
+          int inc = len_r;  // inclusive wave scan
+#pragma unroll
+          for (int off = 1; off < kWave; off <<= 1) {
+            const int v = __shfl_up(inc, off, kWave);
+            if (lane >= off) inc += v;
+          }
+          if (rr < nrows) {
+            rs[rr] = src;
+            ro[rr + 1] = scanned + inc;
+          }
+          scanned += __shfl(inc, kWave - 1, kWave);
+        }
+        if (lane == 0) ro[0] = 0;
+        const int T = scanned;
+        if (!whole && T > kWaveRegionCap) {
+          giveup = true;
+        } else {
+          int rrow = 0;
+          for (int t0 = lane; t0 < T; t0 += 4 * kWave) {
+            float4 c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int t = t0 + u * kWave;
+              const float qnan = __uint_as_float(0x7fc00000u);
+              c[u] = make_float4(qnan, qnan, qnan, 0.f);
+              if (t < T) {
+                while (ro[rrow + 1] <= t) ++rrow;
+                c[u] = sp[rs[rrow] + (t - ro[rrow])];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) consider(c[u]);
+          }
+        }
+      } else {
+        for (int z = Z0; z <= Z1 && !giveup; ++z) {
+          for (int y = Y0; y <= Y1; ++y) {
+            const int rowbase = (z * g.G[1] + y) * g.G[0];
+            const int s = cstart[rowbase + X0], e = cstart[rowbase + X1 + 1];
+            for (int j = s + lane; j < e; j += kWave) consider(sp[j]);
+            scanned += e - s;
+          }
+          if (!whole && scanned > kWaveRegionCap) giveup = true;
+        }
+      }
+      if (giveup) {
+        if (lane == 0) {
+          const int pos = atomicAdd(fb2_count + n, 1);
+          fb2_list[(int64_t)n * P1 + pos] = qi;
+        }
+        break;
+      }
+      // K rounds: wave-wide lexicographic minimum of the list heads; the (unique) winner pops
+      double mine = TopKF64<KC>::empty(), kth = TopKF64<KC>::empty();
+      for (int k = 0; k < kvalid; ++k) {
+        double m = top.key[0];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+          const int hi = __shfl_xor(__double2hiint(m), off, kWave);
+          const int lo = __shfl_xor(__double2loint(m), off, kWave);
+          m = kmin(m, __hiloint2double(hi, lo));
+        }
+        if (lane == k) mine = m;
+        kth = m;
+        if (__double_as_longlong(top.key[0]) == __double_as_longlong(m)) {
+#pragma unroll
+          for (int s2 = 0; s2 + 1 < KC; ++s2) top.key[s2] = top.key[s2 + 1];
+          top.key[KC - 1] = TopKF64<KC>::empty();
+        }
+      }
+      const unsigned kth_bits = (unsigned)__double2hiint(kth);
+      const bool full = kvalid == K && kth_bits < 0x7f800000u;
+      if (whole || (full && __uint_as_float(kth_bits) < lb)) {
+        if (lane < K) {
+          const bool ok = lane < kvalid;
+          idxs[row * K + lane] = ok ? (int64_t)__double2loint(mine) : 0;
+          dists[row * K + lane] = ok ? __int_as_float(__double2hiint(mine)) : 0.0f;
+        }
+        done = true;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launches of one (D, NORM): lane search, then the exact fallbacks for what it could not certify
+// ---------------------------------------------------------------------------
+template <int D, int KC, int NORM>
+static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
+  const int wgs = 256 * 32;  // one wave64 per workgroup, up to 32 waves per CU resident
+  hipLaunchKernelGGL((knn_grid_lane_kernel<D, KC, NORM>), dim3((unsigned)wgs), dim3(kGridWave), 0, a.stream, a.p1,
+                     (const GridCloud*)ws.cloud, (const int*)ws.chunk_prefix, (const float*)ws.edges,
+                     (const int*)ws.cell_start, (const float4*)ws.sorted, (const int*)ws.qlist, ws.fb_count,
+                     ws.fb_list, ws.fb_kth, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
+  if (quad) {
+    int64_t wx = a.P1 / (32 * kQuadQueries);  // a few % of a cloud arrive here
+    wx = wx < 8 ? 8 : wx > 4096 ? 4096 : wx;
+    hipLaunchKernelGGL((knn_grid_quad_kernel<D, KC, NORM>), dim3((unsigned)wx, (unsigned)a.N), dim3(kGridWave), 0,
+                       a.stream, a.p1, (const GridCloud*)ws.cloud, (const float*)ws.edges, (const int*)ws.cell_start,
+                       (const float4*)ws.sorted, (const int*)ws.fb_count, (const int*)ws.fb_list,
+                       (const unsigned*)ws.fb_kth, ws.fb3_count, ws.fb3_list, ws.cell_cap, a.P1, a.P2, a.K, a.idxs,
+                       a.dists);
+  }
+  hipLaunchKernelGGL((knn_grid_wave_kernel<D, KC, NORM>), dim3(kWaveKernelWgsPerCloud, (unsigned)a.N),
+                     dim3(kWaveKernelBlock), 0, a.stream, a.p1, (const GridCloud*)ws.cloud, (const float*)ws.edges,
+                     (const int*)ws.cell_start, (const float4*)ws.sorted,
+                     (const int*)(quad ? ws.fb3_count : ws.fb_count), (const int*)(quad ? ws.fb3_list : ws.fb_list),
+                     ws.fb2_count, ws.fb2_list, ws.cell_cap, a.P1, a.P2, a.K, quad ? 4 : 2, a.idxs, a.dists);
+}
+
+template <int D, int NORM>
+void grid_search_dispatch(const KnnArgs& a, const GridWs& ws, int kc, bool quad) {
+  switch (kc) {
+    case 1: launch_grid_passes<D, 1, NORM>(a, ws, quad); break;
+    case 2: launch_grid_passes<D, 2, NORM>(a, ws, quad); break;
+    case 4: launch_grid_passes<D, 4, NORM>(a, ws, quad); break;
+    case 8: launch_grid_passes<D, 8, NORM>(a, ws, quad); break;
+    case 16: launch_grid_passes<D, 16, NORM>(a, ws, quad); break;
+    default: launch_grid_passes<D, 32, NORM>(a, ws, quad); break;
+  }
+}
+
+// one translation unit per point dimension (knn_grid_d1/2/3.hip)
+void grid_search_d1(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool quad);
+void grid_search_d2(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool quad);
+void grid_search_d3(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool quad);
+
+}  // namespace pointops

@@ -90,4 +90,75 @@ __device__ __forceinline__ void bitonic_merge(unsigned (&a)[N]) {  // bitonic ->
   }
 }
 
+// ---------------------------------------------------------------------------
+// 64-bit keys through the FP64 pipe.  A key (fp32 distance bits << 32 | index) with distance >= +0 and
+// not NaN is the bit pattern of a non-negative, non-NaN double (the top 12 bits are 0x7f8 at most, never
+// 0x7ff), and for such doubles value order == unsigned bit-pattern order (denormal doubles included: FP64
+// denormals are never flushed on gfx9).  v_min_f64 / v_max_f64 return one operand unchanged, so a
+// compare-exchange is TWO instructions (10-11 cycles per wave on a SIMD, tools/ce_microbench.hip)
+// instead of v_cmp_lt_u64 + mask + 4 v_bfi_b32 (27 cycles); exactness against an integer sort is
+// checked by the same tool over denormal / zero / +inf / tie-heavy key sets.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double kmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double kmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void key_ce(double& a, double& b, bool) {
+  const double lo = kmin(a, b), hi = kmax(a, b);
+  a = lo;
+  b = hi;
+}
+template <int N>
+__device__ __forceinline__ void bitonic_sort(double (&a)[N]) {  // ascending
+#pragma unroll
+  for (int i = 0; i < SortNet<N>::kSize; ++i) key_ce(a[SortNet<N>::kA[i]], a[SortNet<N>::kB[i]], true);
+}
+template <int N>
+__device__ __forceinline__ void bitonic_merge(double (&a)[N]) {  // bitonic -> ascending
+#pragma unroll
+  for (int j = N >> 1; j > 0; j >>= 1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int l = i ^ j;
+      if (l > i) key_ce(a[i], a[l], true);
+    }
+  }
+}
+
+// Sorted (ascending) register top-K on such keys, candidates in ARBITRARY index order (grid searches).
+template <int KC>
+struct TopKF64 {
+  double key[KC];
+  __device__ __forceinline__ static double empty() { return __hiloint2double(0x7f800000, 0x7fffffff); }  // (+inf, INT_MAX)
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int i = 0; i < KC; ++i) key[i] = empty();
+  }
+  __device__ __forceinline__ static double make(float d, int j) { return __hiloint2double(__float_as_int(d), j); }
+  __device__ __forceinline__ unsigned worst_bits() const { return (unsigned)__double2hiint(key[KC - 1]); }
+  // distance bits of the K-th best (1 <= K <= KC, runtime): what a query needs certified
+  __device__ __forceinline__ unsigned kth_bits(int K) const {
+    unsigned b = (unsigned)__double2hiint(key[KC - 1]);
+    if (K < KC) {  // wave-uniform branch; a select chain (indexing the register array by K would go through scratch)
+#pragma unroll
+      for (int t = 0; t < KC - 1; ++t) b = (t == K - 1) ? (unsigned)__double2hiint(key[t]) : b;
+    }
+    return b;
+  }
+  // branch-free sorted insert: slot i takes min(key[i], max(key[i-1], k)); 2 KC - 1 FP64 min/max
+  __device__ __forceinline__ void insert(double k) {
+#pragma unroll
+    for (int i = KC - 1; i > 0; --i) key[i] = kmin(key[i], kmax(key[i - 1], k));
+    key[0] = kmin(key[0], k);
+  }
+  __device__ __forceinline__ float dist_at(int k) const { return __int_as_float(__double2hiint(key[k])); }
+  __device__ __forceinline__ int idx_at(int k) const { return __double2loint(key[k]); }
+};
+
 }  // namespace pointops

@@ -29,6 +29,7 @@
 //     __device__ float value(const Regs&, int c) const; };                    // addend of channel c
 #pragma once
 #include "common.h"
+#include "debug.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -64,8 +65,8 @@ struct TiledPlan {
   dim3 grid;
 };
 
-// tiles when the table is large and the target splits into few tiles; `env_prefix`_MODE = atomic |
-// tiled and `env_prefix`_SPLIT override the choice (A/B measurements and tests)
+// tiles when the table is large and the target splits into few tiles; the debug knobs `env_mode` = a(tomic) |
+// t(iled) and `env_split` override the choice (A/B measurements and tests; debug.h)
 static inline TiledPlan tiled_plan(int64_t N, int64_t rows, int64_t K, int64_t M, int C, const char* env_mode,
                                    const char* env_split) {
   TiledPlan p{false, 0, 1, dim3(1)};
@@ -73,15 +74,14 @@ static inline TiledPlan tiled_plan(int64_t N, int64_t rows, int64_t K, int64_t M
   p.parts = (int)ceil_div(M, tiled_tile_rows(C));
   const bool fits = rows * K < (1LL << 31) - (1 << 20);
   p.tiled = fits && p.parts <= 16 && N * rows * K >= (1 << 21);
-  if (const char* e = getenv(env_mode)) {
-    if (e[0] == 'a') p.tiled = false;
-    if (e[0] == 't') p.tiled = fits && p.parts <= 64;
-  }
+  const char mode = debug_knob_c(env_mode);
+  if (mode == 'a') p.tiled = false;
+  if (mode == 't') p.tiled = fits && p.parts <= 64;
   if (!p.tiled) return p;
   // few clouds: split the rows so that ~256 workgroups exist; partial tiles meet with atomics
   const int64_t wgs = N * p.parts;
   if (wgs < 192) p.S = (int)std::min<int64_t>(ceil_div(256, wgs), std::max<int64_t>(1, rows / 4096));
-  if (const char* e = getenv(env_split)) p.S = std::max(1, atoi(e));
+  p.S = std::max<int>(1, (int)debug_knob(env_split, p.S));
   const int64_t groups = ceil_div(N * p.S, kXcds);
   if (groups * kXcds * p.parts >= (1LL << 31)) {
     p.tiled = false;

@@ -1,0 +1,73 @@
+"""Host-side helpers shared by the functional wrappers: argument checks of point-set pairs, default
+`lengths`, fp32 coercion for backward passes, and the nondeterminism alert of the atomic scatter kernels.
+
+The `ValueError` texts are the reference's (pytorch3d_pointops/functions/knn.py:174-176,
+functions/ball_query.py:120-123); everything else is this package's own plumbing.
+"""
+import warnings
+from typing import Optional, Tuple
+
+import torch
+
+_LENGTHS_CACHE = {}
+
+
+def full_lengths(n: int, p: int, device) -> torch.Tensor:
+    """(n,) int64 tensor filled with p -- the default `lengths` (reference: functions/knn.py:184-187).
+    The kernels only read it, so one tensor per (n, p, device) is kept and reused: it saves a fill launch per
+    call, and passing the SAME tensor for both point sets lets the C ABI recognise a self-query (p1 is p2)."""
+    key = (int(n), int(p), str(device))
+    t = _LENGTHS_CACHE.get(key)
+    if t is None:
+        if len(_LENGTHS_CACHE) > 64:
+            _LENGTHS_CACHE.clear()
+        t = torch.full((n,), p, dtype=torch.int64, device=device)
+        _LENGTHS_CACHE[key] = t
+    return t
+
+
+def point_pair(p1: torch.Tensor, p2: torch.Tensor, lengths1: Optional[torch.Tensor],
+               lengths2: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Validated, contiguous (p1, p2, lengths1, lengths2) of a query / reference pair of padded clouds."""
+    if p1.shape[0] != p2.shape[0]:
+        raise ValueError("pts1 and pts2 must have the same batch dimension.")
+    if p1.shape[2] != p2.shape[2]:
+        raise ValueError("pts1 and pts2 must have the same point dimension.")
+    same = p1 is p2
+    p1 = p1.contiguous()
+    p2 = p1 if same else p2.contiguous()
+    n = p1.shape[0]
+    if lengths1 is None:
+        lengths1 = full_lengths(n, p1.shape[1], p1.device)
+    if lengths2 is None:
+        lengths2 = full_lengths(n, p2.shape[1], p1.device)
+    return p1, p2, lengths1, lengths2
+
+
+def as_f32(t: torch.Tensor) -> torch.Tensor:
+    return t if t.dtype == torch.float32 else t.float()
+
+
+def alert_not_deterministic(caller: str) -> None:
+    """What `at::globalContext().alertNotDeterministic(caller)` does in the reference's CUDA backward
+    (csrc/knn/knn.cu:538): under `torch.use_deterministic_algorithms(True)` an op whose result depends on
+    the order of fp32 atomic adds raises (or warns, with warn_only=True)."""
+    if torch.are_deterministic_algorithms_enabled():
+        msg = (f"{caller} does not have a deterministic implementation, but you set "
+               "'torch.use_deterministic_algorithms(True)'. You can turn off determinism just for this operation, "
+               "or you can use the 'warn_only=True' option, if that's acceptable for your application.")
+        if torch.is_deterministic_algorithms_warn_only_enabled():
+            warnings.warn(msg, UserWarning, stacklevel=3)
+        else:
+            raise RuntimeError(msg)
+
+
+def neighbor_backward(saved, norm: int, grad_dists: torch.Tensor, caller: str):
+    """Shared backward of knn_points and ball_query: (grad_p1, grad_p2) from the neighbour table
+    (reference: functions/knn.py:96-111, functions/ball_query.py:36-52).  idx == -1 entries are skipped
+    by the kernel."""
+    from .. import _C
+
+    p1, p2, lengths1, lengths2, idx = saved
+    alert_not_deterministic(caller)
+    return _C.knn_points_backward(as_f32(p1), as_f32(p2), lengths1, lengths2, idx, norm, as_f32(grad_dists))

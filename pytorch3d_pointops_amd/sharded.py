@@ -73,6 +73,16 @@ def all_gather_losses(local: torch.Tensor, counts: Sequence[int], group=None) ->
     return torch.cat([full[r * m:r * m + counts[r]] for r in range(world)])
 
 
+def plan_shards(num_clouds: int, world_size: int, costs: Optional[Sequence[float]] = None) -> List[List[int]]:
+    """Global cloud ids owned by every rank.  Without `costs`: the contiguous `shard_bounds` split.
+    With `costs` (ragged chamfer: len1[n]*len2[n]): cost-balanced placement (`balanced_assignment`),
+    so a batch of 20k..200k-point clouds does not leave ranks idle behind the one that drew the big clouds."""
+    if costs is None:
+        return [list(range(s, e)) for s, e in shard_bounds(num_clouds, world_size)]
+    assert len(costs) == num_clouds
+    return balanced_assignment(costs, world_size)
+
+
 def sharded_chamfer_distance(
     x_local, y_local,
     num_clouds_total: int,
@@ -82,16 +92,23 @@ def sharded_chamfer_distance(
     batch_reduction: Optional[str] = "mean",
     group=None,
     local_fn: Optional[Callable] = None,
+    cloud_counts: Optional[Sequence[int]] = None,
+    assignment: Optional[Sequence[Sequence[int]]] = None,
     **chamfer_kwargs,
 ):
-    """chamfer_distance over a batch sharded across ranks (contiguous `shard_bounds` split).
+    """chamfer_distance over a batch sharded across ranks.
+
+    Placement: by default the contiguous `shard_bounds` split; `cloud_counts` gives explicit per-rank
+    counts of a contiguous split; `assignment` (from `plan_shards(..., costs)`) gives the global cloud
+    ids of every rank -- rank r's local tensors then hold clouds assignment[r] in that order, and the
+    gathered vector is un-permuted into global cloud order.
 
     Each rank computes the per-cloud losses of ITS clouds with the single-GPU path
-    (`batch_reduction=None`), the (B/G,) vectors are all-gathered, and the reference's
-    batch reduction (functions/chamfer.py:192-214) is applied to the full (B,) vector, so
-    the value equals the single-process result on the concatenated batch.
+    (`batch_reduction=None`), the per-rank vectors are all-gathered, and the reference's
+    batch reduction (functions/chamfer.py:192-214) is applied to the full (B,) vector in global cloud
+    order, so the value equals the single-process result on the whole batch whatever the placement.
     Returns (loss, loss_features) like chamfer_distance; per-cloud vectors when
-    batch_reduction is None (full batch, rank order).
+    batch_reduction is None (full batch, global cloud order).
     `local_fn` (tests only) replaces the local per-cloud computation.
     """
     if batch_reduction not in (None, "mean", "sum"):
@@ -99,18 +116,42 @@ def sharded_chamfer_distance(
     if chamfer_kwargs.get("point_reduction", "mean") is None:
         raise ValueError("sharded_chamfer_distance needs a point_reduction (per-cloud scalars)")
     world = dist.get_world_size(group)
-    counts = [e - s for s, e in shard_bounds(num_clouds_total, world)]
+    if assignment is not None:
+        if len(assignment) != world or sorted(i for a in assignment for i in a) != list(range(num_clouds_total)):
+            raise ValueError("assignment must list every cloud id exactly once over world_size ranks")
+        counts = [len(a) for a in assignment]
+    elif cloud_counts is not None:
+        counts = [int(c) for c in cloud_counts]
+        if len(counts) != world or sum(counts) != num_clouds_total:
+            raise ValueError("cloud_counts must have world_size entries that sum to num_clouds_total")
+    else:
+        counts = [e - s for s, e in shard_bounds(num_clouds_total, world)]
     if local_fn is None:
         from .functions.chamfer import chamfer_distance
 
         def local_fn(x, y, **kw):
             return chamfer_distance(x, y, batch_reduction=None, **kw)
 
+    unpermute = None
+    if assignment is not None:
+        order = [i for a in assignment for i in a]  # gathered position -> global cloud id
+        if order != list(range(num_clouds_total)):
+            inv = [0] * num_clouds_total
+            for pos, gid in enumerate(order):
+                inv[gid] = pos
+
+            def unpermute(v):
+                return v[torch.tensor(inv, dtype=torch.int64, device=v.device)]
+
+    def gather(v):
+        full = all_gather_losses(v, counts, group)
+        return unpermute(full) if unpermute is not None else full
+
     loss_l, feat_l = local_fn(x_local, y_local, weights=weights_local, **chamfer_kwargs)
-    loss = all_gather_losses(loss_l, counts, group)
+    loss = gather(loss_l)
     feats: Optional[Dict[str, torch.Tensor]] = None
     if feat_l is not None:
-        feats = {k: all_gather_losses(v, counts, group) for k, v in sorted(feat_l.items())}
+        feats = {k: gather(v) for k, v in sorted(feat_l.items())}
     if batch_reduction is None:
         return loss, feats
     loss = loss.sum()

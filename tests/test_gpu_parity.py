@@ -150,7 +150,7 @@ def test_knn_wide_shapes(dev, oracle, monkeypatch, name):
     oi, od = oracle.knn_points_idx(p1, p2, l1, l2, norm, K)
     assert np.array_equal(idx.cpu().numpy(), oi)
     assert np.array_equal(bits(dists.cpu().numpy()), bits(od))
-    monkeypatch.setenv("POINTOPS_KNN_GENERIC", "1")
+    monkeypatch.setenv("POINTOPS_DEBUG", "knn_generic=1")
     idx2, dists2 = _C.knn_points_idx(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm, K, 0)
     assert torch.equal(idx, idx2) and torch.equal(dists.view(torch.int32), dists2.view(torch.int32))
 
@@ -174,20 +174,27 @@ def test_knn_grid_adversarial(dev, oracle, name):
     assert torch.equal(r2.idx, r.idx) and torch.equal(r2.dists, r.dists)
 
 
-@pytest.mark.parametrize("mode", ["quad", "block", "noquad"])
+@pytest.mark.parametrize("mode", ["quad", "noquad", "self"])
 @pytest.mark.parametrize("name", ["clustered", "lattice_ties", "disjoint_far", "half_in_cluster", "k32", "k1", "d2"])
 def test_knn_grid_alternative_passes(dev, oracle, monkeypatch, mode, name):
     """The passes the automatic choice only takes on large clouds (the radius-2 quad search needs >= 32768
-    queries per cloud) or never (block-shared search), forced on the adversarial distributions."""
+    queries per cloud), forced on the adversarial distributions; "self": the queries ARE the points (same
+    buffer), so the point sort doubles as the query order -- against the run with that reuse switched off."""
     from pytorch3d_pointops_amd.functions import knn_points
 
-    if mode == "quad":
-        monkeypatch.setenv("POINTOPS_GRID_QUAD", "1")
-    elif mode == "noquad":
-        monkeypatch.setenv("POINTOPS_GRID_QUAD", "0")
-    else:
-        monkeypatch.setenv("POINTOPS_GRID_MODE", "block")
     p1, p2, K = _grid_adversarial_cases()[name]
+    if mode == "self":
+        l2 = np.array([p2.shape[1], max(K - 2, 1)])
+        t, lt = G(p2, dev), G(l2, dev)
+        r = knn_points(t, t, lt, lt, K=K, version=3)  # same tensors: one sort
+        oi, od = oracle.knn_points_idx(p2, p2, l2, l2, 2, K)
+        assert np.array_equal(r.idx.cpu().numpy(), oi)
+        assert np.array_equal(bits(r.dists.cpu().numpy()), bits(od))
+        monkeypatch.setenv("POINTOPS_DEBUG", "grid_same=0")
+        r2 = knn_points(t, t, lt, lt, K=K, version=3)
+        assert torch.equal(r2.idx, r.idx) and torch.equal(r2.dists, r.dists)
+        return
+    monkeypatch.setenv("POINTOPS_DEBUG", "grid_quad=1" if mode == "quad" else "grid_quad=0")
     l1 = np.array([p1.shape[1], p1.shape[1] // 3])
     l2 = np.array([p2.shape[1], max(K - 2, 1)])
     r = knn_points(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), K=K, version=3)
@@ -246,9 +253,7 @@ def test_knn_backward_modes(dev, oracle, monkeypatch, mode, split, D, norm, K):
     oracle's CPU loop (knn_cpu.cpp:75-128) on the SAME neighbour table."""
     from pytorch3d_pointops_amd import _C
 
-    monkeypatch.setenv("POINTOPS_KNN_BWD_MODE", mode)
-    if split:
-        monkeypatch.setenv("POINTOPS_KNN_BWD_SPLIT", split)
+    monkeypatch.setenv("POINTOPS_DEBUG", f"knn_bwd_mode={mode}" + (f",knn_bwd_split={split}" if split else ""))
     N, P1, P2 = 3, 2500, 30000
     p1 = cases.cloud(1500 + D, (N, P1, D))
     p2 = cases.cloud(1510 + D, (N, P2, D))
@@ -296,9 +301,7 @@ def test_gather_backward_modes(dev, monkeypatch, mode, split, U):
     (functions/knn.py:236-248: k >= lengths[n] zeroed; utils.py:53-63: -1 rows zeroed)."""
     from pytorch3d_pointops_amd import _C, synth
 
-    monkeypatch.setenv("POINTOPS_GATHER_BWD_MODE", mode)
-    if split:
-        monkeypatch.setenv("POINTOPS_GATHER_BWD_SPLIT", split)
+    monkeypatch.setenv("POINTOPS_DEBUG", f"gather_bwd_mode={mode}" + (f",gather_bwd_split={split}" if split else ""))
     N, L, K, M = 2, 3000, 8, 20000
     idx = synth.randint(1601, -1, M - 1, (N, L, K))
     idx[0, ::7, :] = 3  # many rows onto one target row
@@ -393,7 +396,7 @@ def test_ball_query_grid_matches_golden(dev, monkeypatch, name):
 
     g = load_golden("ball_query")
     c = cases.ball_query_cases()[name]
-    monkeypatch.setenv("POINTOPS_BALL_GRID", "1")
+    monkeypatch.setenv("POINTOPS_DEBUG", "ball_grid=1")
     idx, d = _C.ball_query(G(c["p1"], dev), G(c["p2"], dev), G(c["l1"], dev), G(c["l2"], dev), c["K"], c["radius"])
     assert np.array_equal(idx.cpu().numpy(), g[name + "/idx"].astype(np.int64))
     assert np.array_equal(bits(d.cpu().numpy()), bits(g[name + "/dists"]))
@@ -413,12 +416,12 @@ def test_ball_query_grid_vs_oracle(dev, oracle, monkeypatch, radius, K, D):
     p1[1] = (p1[1] ** np.float32(3.0)).astype(np.float32) + np.float32(10.0)
     l1 = np.array([3000, 1234, 77])
     l2 = np.array([20000, 6000, 0])
-    monkeypatch.setenv("POINTOPS_BALL_GRID", "1")
+    monkeypatch.setenv("POINTOPS_DEBUG", "ball_grid=1")
     idx, d = _C.ball_query(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), K, radius)
     oi, od = oracle.ball_query(p1, p2, l1, l2, K, radius)
     assert np.array_equal(idx.cpu().numpy(), oi)
     assert np.array_equal(bits(d.cpu().numpy()), bits(od))
-    monkeypatch.setenv("POINTOPS_BALL_GRID", "0")
+    monkeypatch.setenv("POINTOPS_DEBUG", "ball_grid=0")
     idx0, d0 = _C.ball_query(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), K, radius)
     assert torch.equal(idx, idx0) and torch.equal(d.view(torch.int32), d0.view(torch.int32))
 
@@ -436,8 +439,7 @@ def test_ball_query_grid_adversarial(dev, oracle, monkeypatch, name):
     radius = 0.25 * scale if name == "lattice_ties" else 0.06 * scale
     l1 = np.array([p1.shape[1], p1.shape[1] // 3])
     l2 = np.array([p2.shape[1], 5])
-    monkeypatch.setenv("POINTOPS_BALL_GRID", "1")
-    monkeypatch.setenv("POINTOPS_BALL_FACTOR", "0")  # always the grid where one can be built
+    monkeypatch.setenv("POINTOPS_DEBUG", "ball_grid=1,ball_factor=0")  # always the grid where one can be built
     for K in (4, 20):
         idx, d = _C.ball_query(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), K, radius)
         oi, od = oracle.ball_query(p1, p2, l1, l2, K, radius)

@@ -87,7 +87,24 @@ def _worker(rank, world, port, q):
         loss.backward()
         # raw gather with uneven counts
         vec = all_gather_losses(torch.arange(s, e, dtype=torch.float32), [3, 2])
-        q.put((rank, float(loss), xt.grad.numpy().copy(), yt.grad.numpy().copy(), vec.numpy().copy()))
+        # cost-balanced placement of the ragged batch (cost = len1 * len2): rank r owns clouds plan[r]
+        from pytorch3d_pointops_amd.sharded import plan_shards
+
+        plan = plan_shards(B, world, costs=(xl * yl).tolist())
+        ids = plan[rank]
+        xb = torch.from_numpy(x[ids]).requires_grad_(True)
+        yb = torch.from_numpy(y[ids]).requires_grad_(True)
+
+        def local_fn_b(xx, yy, weights=None, **kw):
+            return _oracle_chamfer_per_cloud(xx, yy, xl[ids], yl[ids], weights), None
+
+        per_b, _ = sharded_chamfer_distance(xb, yb, B, weights_local=torch.from_numpy(w[ids]), batch_reduction=None,
+                                            local_fn=local_fn_b, assignment=plan)
+        loss_b, _ = sharded_chamfer_distance(xb, yb, B, weights_local=torch.from_numpy(w[ids]),
+                                             batch_reduction="mean", local_fn=local_fn_b, assignment=plan)
+        loss_b.backward()
+        q.put((rank, float(loss), xt.grad.numpy().copy(), yt.grad.numpy().copy(), vec.numpy().copy(),
+               plan, per_b.detach().numpy().copy(), float(loss_b), xb.grad.numpy().copy()))
     finally:
         dist.destroy_process_group()
 
@@ -125,3 +142,14 @@ def test_sharded_chamfer_matches_single_process_gloo():
     assert np.allclose(gx, xt.grad.numpy(), atol=1e-7) and np.allclose(gy, yt.grad.numpy(), atol=1e-7)
     assert np.array_equal(res[0][3], np.arange(5, dtype=np.float32))
     assert np.array_equal(res[1][3], np.arange(5, dtype=np.float32))
+    # balanced placement: a non-contiguous plan, per-cloud vector back in GLOBAL cloud order, same loss / grads
+    plan = res[0][4]
+    assert plan == res[1][4] and sorted(plan[0] + plan[1]) == list(range(B))
+    assert plan != [[0, 1, 2], [3, 4]]
+    cost = (xl * yl).astype(np.float64)
+    loads = [cost[ids].sum() for ids in plan]
+    assert abs(loads[0] - loads[1]) <= cost.max()
+    for r in range(world):
+        assert np.allclose(res[r][5], per.detach().numpy(), atol=1e-7)
+        assert abs(res[r][6] - float(full)) <= 1e-6
+        assert np.allclose(res[r][7], xt.grad.numpy()[plan[r]], atol=1e-7)

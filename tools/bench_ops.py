@@ -54,10 +54,10 @@ def main():
         emit("ball_query B=16 N=131072 r=0.2 K=32", ms, mn, algo_GBs=outb / ms / 1e6)
         for (rr, kk, b) in ((0.05, 32, 16), (0.02, 32, 16), (0.01, 16, 16), (0.02, 32, 2)):
             for g in ("1", "0"):
-                os.environ["POINTOPS_BALL_GRID"] = g
+                os.environ["POINTOPS_DEBUG"] = "ball_grid=" + g
                 ms2, mn2 = timeit(lambda: _C.ball_query(pts[:b], pts[:b], L[:b], L[:b], kk, rr), warmup=1, iters=3)
                 emit(f"ball_query B={b} N=131072 r={rr} K={kk} [grid={g}]", ms2, mn2)
-        del os.environ["POINTOPS_BALL_GRID"]
+        del os.environ["POINTOPS_DEBUG"]
         ms, mn = timeit(lambda: ball_query(pts, pts, L, L, K=32, radius=0.2, return_nn=True))
         emit("ball_query(+return_nn) B=16 N=131072", ms, mn, algo_GBs=(outb + Bc * Pc * 32 * 12) / ms / 1e6)
     if "fps" in ops:
@@ -110,11 +110,11 @@ def main():
         emit("knn_gather B=8 N=16384 K=16 U=64", ms, mn, algo_GBs=(8 * 16384 * 16 * (8 + 256) + 8 * 16384 * 256) / ms / 1e6)
         gg = torch.from_numpy(synth.uniform_f32(63, (Bg, Pg, Kg, 3))).to(dev)
         for mode in ("tiled", "atomic"):
-            os.environ["POINTOPS_GATHER_BWD_MODE"] = mode
+            os.environ["POINTOPS_DEBUG"] = "gather_bwd_mode=" + mode
             ms, mn = timeit(lambda: _C.gather_neighbors_backward(gg, ig, None, Pg))
             emit(f"knn_gather backward B=32 N=65536 K=16 U=3 [{mode}]", ms, mn,
                  algo_GBs=(Bg * Pg * Kg * (8 + 12) + Bg * Pg * 12) / ms / 1e6)
-        del os.environ["POINTOPS_GATHER_BWD_MODE"]
+        del os.environ["POINTOPS_DEBUG"]
     if "cov" in ops:
         Bv, Pv, Kv = 8, 65536, 16
         kn = torch.from_numpy(synth.uniform_f32(91, (Bv, Pv, Kv, 3))).to(dev)
@@ -137,21 +137,21 @@ def main():
         gd = torch.from_numpy(synth.uniform_f32(83, (Bb, Pb, Kb))).to(dev)
         algo = Bb * Pb * Kb * (8 + 4) + 3 * Bb * Pb * 12 + Bb * Pb * 12  # idx + grad_dists, p1/p2 reads + 2 grads
         for mode in ("tiled", "atomic"):
-            os.environ["POINTOPS_KNN_BWD_MODE"] = mode
+            os.environ["POINTOPS_DEBUG"] = "knn_bwd_mode=" + mode
             ms, mn = timeit(lambda: _C.knn_points_backward(a, c, Lb, Lb, idx, 2, gd))
             emit(f"knn_points_backward B=32 N=65536 K=16 [{mode}]", ms, mn, algo_GBs=algo / ms / 1e6,
                  scatter_adds_per_s=Bb * Pb * Kb * 3 / ms * 1e3)
-        del os.environ["POINTOPS_KNN_BWD_MODE"]
+        del os.environ["POINTOPS_DEBUG"]
         for (b, n, k) in ((1, 65536, 16), (4, 16384, 16), (8, 65536, 1)):
             a2, c2 = a[:b, :n].contiguous(), c[:b, :n].contiguous()
             L2 = torch.full((b,), n, dtype=torch.int64, device=dev)
             idx2, _ = _C.knn_points_idx(a2, c2, L2, L2, 2, k, -1)
             gd2 = gd[:b, :n, :k].contiguous()
             for mode in ("tiled", "atomic"):
-                os.environ["POINTOPS_KNN_BWD_MODE"] = mode
+                os.environ["POINTOPS_DEBUG"] = "knn_bwd_mode=" + mode
                 ms, mn = timeit(lambda: _C.knn_points_backward(a2, c2, L2, L2, idx2, 2, gd2))
                 emit(f"knn_points_backward B={b} N={n} K={k} [{mode}]", ms, mn)
-            del os.environ["POINTOPS_KNN_BWD_MODE"]
+            del os.environ["POINTOPS_DEBUG"]
     if "knn_small" in ops:
         for (b, n, k) in ((2, 1024, 8), (32, 4096, 16), (8, 65536, 1)):
             a = torch.from_numpy(synth.uniform_f32(71, (b, n, 3))).to(dev)

@@ -1,4 +1,4 @@
-"""Cell-occupancy sweep of the grid KNN per K (POINTOPS_GRID_C_SCALE multiplies grid_tuning's target)."""
+"""Cell-occupancy sweep of the grid KNN per K (the debug knob grid_c_scale multiplies grid_tuning's target)."""
 import json
 import os
 import sys
@@ -35,6 +35,6 @@ SCALES = tuple(os.environ.get("POINTOPS_SWEEP_SCALES", "0.5,0.7,1.0,1.4,2.0,2.8,
 for K in KS:
     out = {}
     for sc in SCALES:
-        os.environ["POINTOPS_GRID_C_SCALE"] = sc
+        os.environ["POINTOPS_DEBUG"] = "grid_c_scale=" + sc
         out[sc] = round(timeit(lambda: _C.knn_points_idx(x, y, L, L, 2, K, 3)), 4)
     print(json.dumps({"K": K, "B": B, "N": N, "ms_by_scale": out}), flush=True)
