@@ -8,3 +8,6 @@ C ABI (``include/pointops_amd.h``).  There is no CPU fallback: a missing library
 or a CPU tensor raises.
 """
 __version__ = "0.1.0"
+
+from . import _C  # noqa: E402,F401  loads libpointops_amd.so (raises when it is missing)
+from . import ops  # noqa: E402,F401  registers torch.ops.pointops_amd.*

@@ -48,5 +48,8 @@ def ball_query(
     padded with 0 (else None).  `lengths1` / `lengths2` (N,) give the valid points per cloud.
     """
     p1, p2, lengths1, lengths2 = point_pair(p1, p2, lengths1, lengths2)
-    dists, idx = _BallQueryFn.apply(p1, p2, lengths1, lengths2, K, radius)
+    if torch.compiler.is_compiling():  # traced graphs see the registered op (pytorch3d_pointops_amd/ops.py)
+        idx, dists = torch.ops.pointops_amd.ball_query(p1, p2, lengths1, lengths2, K, radius)
+    else:
+        dists, idx = _BallQueryFn.apply(p1, p2, lengths1, lengths2, K, radius)
     return _KNN(dists=dists, idx=idx, knn=masked_gather(p2, idx) if return_nn else None)

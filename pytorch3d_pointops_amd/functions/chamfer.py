@@ -1,17 +1,17 @@
-"""chamfer_distance -- same API as the reference's functions/chamfer.py.
+"""chamfer_distance -- the API of the reference's functions/chamfer.py (:217-365) on the HIP kernels.
 
-reference: pytorch3d_pointops/functions/chamfer.py:17-35 (reduction validation),
-:38-82 (_handle_pointcloud_input), :85-189 (_chamfer_distance_single_direction),
-:192-214 (_apply_batch_reduction), :217-365 (chamfer_distance).
+Structure on MI355X.  A direction (x -> y) is ONE autograd node `_chamfer_direction`: the K=1 exact grid
+search, then one fused kernel for the masked / weighted / length-normalised per-cloud sums of the point term
+and of every cosine feature term, with a closed-form fused backward (csrc/chamfer.hip) -- instead of the
+reference's chain of ~25 torch kernels and five host syncs per direction (:85-189).  Reductions the fused
+kernel does not cover (point_reduction "max" / None, exotic feature shapes) take the composed path
+`_direction_composed`, built from knn_points / knn_gather and the fused masked reduction `_masked_point_reduce`.
 
-Structure on MI355X: each direction is one K=1 HIP KNN scan (register top-1,
-scalar-path streaming of the other cloud) followed by ONE fused masked
-reduction kernel (mask rows >= lengths, sum over points, * weights,
-/ clamp(lengths,1)) with a closed-form custom backward, instead of the reference's
-chain of ~6 elementwise/reduction torch kernels and host syncs per direction.  The
-cosine feature term gathers neighbour features with the fused HIP gather.
+Layout of this module: `_Terms` carries what one direction produces (the point term and a dict of feature
+terms); `_combine` merges the two directions per reduction mode; `_reduce_batch` applies the batch reduction
+to every term alike.  Error texts are the reference's (:29-35, :57-80, :120-126, :291-296).
 """
-from typing import Union
+from typing import Dict, NamedTuple, Optional, Union
 
 import torch
 import torch.nn.functional as F
@@ -19,62 +19,66 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
+from ._common import alert_not_deterministic
 from .knn import knn_gather, knn_points
 
 
+class _Terms(NamedTuple):
+    """Loss terms of one direction (or of both, combined): `points` and one entry per feature name
+    (None = no feature loss requested).  Shapes: (N,) after a point reduction, (N, P) without one."""
+    points: object
+    feats: Optional[Dict[str, object]]
+
+    def map(self, fn):
+        return _Terms(fn(self.points), None if self.feats is None else {k: fn(v) for k, v in self.feats.items()})
+
+
 def _is_pointclouds(obj) -> bool:
-    # The reference tests isinstance(points, Pointclouds) (functions/chamfer.py:49).
-    # Accept our own container and any Pointclouds-like object exposing the three
-    # accessors the reference calls (points_padded / num_points_per_cloud / features_padded).
-    return (
-        not torch.is_tensor(obj)
-        and hasattr(obj, "points_padded")
-        and hasattr(obj, "num_points_per_cloud")
-        and hasattr(obj, "features_padded")
-    )
+    # The reference tests isinstance(points, Pointclouds) (functions/chamfer.py:49).  Our own container and
+    # any object with the three accessors the reference calls qualify.
+    return not torch.is_tensor(obj) and all(
+        hasattr(obj, a) for a in ("points_padded", "num_points_per_cloud", "features_padded"))
 
 
-def _validate_chamfer_reduction_inputs(
-    batch_reduction: Union[str, None], point_reduction: Union[str, None]
-) -> None:
-    if batch_reduction is not None and batch_reduction not in ["mean", "sum"]:
-        raise ValueError('batch_reduction must be one of ["mean", "sum"] or None')
-    if point_reduction is not None and point_reduction not in ["mean", "sum", "max"]:
-        raise ValueError('point_reduction must be one of ["mean", "sum", "max"] or None')
+def _validate_chamfer_reduction_inputs(batch_reduction: Union[str, None], point_reduction: Union[str, None]) -> None:
+    allowed = {"batch_reduction": (batch_reduction, ("mean", "sum")),
+               "point_reduction": (point_reduction, ("mean", "sum", "max"))}
+    for name, (value, modes) in allowed.items():
+        if value is not None and value not in modes:
+            raise ValueError(f"{name} must be one of [{', '.join(chr(34) + m + chr(34) for m in modes)}] or None")
     if point_reduction is None and batch_reduction is not None:
         raise ValueError("Batch reduction must be None if point_reduction is None")
 
 
+def _feature_dims_ok(features) -> None:
+    if isinstance(features, dict):
+        for name, t in features.items():
+            if t is not None and t.ndim != 3:
+                raise ValueError(f"Expected {name} to be of shape (N, P, C)")
+    elif torch.is_tensor(features) and features.ndim != 3:
+        raise ValueError("Expected features to be of shape (N, P, C)")
+
+
 def _handle_pointcloud_input(points, lengths, features):
+    """(padded points (N,P,D), lengths (N,), features) of a tensor or Pointclouds-like argument."""
     if _is_pointclouds(points):
-        X = points.points_padded()
-        lengths = points.num_points_per_cloud()
-        features = points.features_padded()  # dict (possibly empty)
-    elif torch.is_tensor(points):
-        if points.ndim != 3:
-            raise ValueError("Expected points to be of shape (N, P, D)")
-        X = points
-        if lengths is not None:
-            if lengths.ndim != 1 or lengths.shape[0] != X.shape[0]:
-                raise ValueError("Expected lengths to be of shape (N,)")
-            if lengths.max() > X.shape[1]:
-                raise ValueError("A length value was too long")
-        if lengths is None:
-            lengths = torch.full((X.shape[0],), X.shape[1], dtype=torch.int64, device=points.device)
-        if features is not None:
-            if isinstance(features, dict):
-                for feature_name, feature_tensor in features.items():
-                    if feature_tensor is not None and feature_tensor.ndim != 3:
-                        raise ValueError(f"Expected {feature_name} to be of shape (N, P, C)")
-            elif torch.is_tensor(features) and features.ndim != 3:
-                raise ValueError("Expected features to be of shape (N, P, C)")
+        return points.points_padded(), points.num_points_per_cloud(), points.features_padded()
+    if not torch.is_tensor(points):
+        raise ValueError("The input pointclouds should be either Pointclouds objects or torch.Tensor of shape "
+                         "(minibatch, num_points, 3).")
+    if points.ndim != 3:
+        raise ValueError("Expected points to be of shape (N, P, D)")
+    n, p = points.shape[:2]
+    if lengths is None:
+        lengths = torch.full((n,), p, dtype=torch.int64, device=points.device)
     else:
-        raise ValueError(
-            "The input pointclouds should be either "
-            + "Pointclouds objects or torch.Tensor of shape "
-            + "(minibatch, num_points, 3)."
-        )
-    return X, lengths, features
+        if lengths.ndim != 1 or lengths.shape[0] != n:
+            raise ValueError("Expected lengths to be of shape (N,)")
+        if lengths.max() > p:
+            raise ValueError("A length value was too long")
+    if features is not None:
+        _feature_dims_ok(features)
+    return points, lengths, features
 
 
 class _masked_point_reduce(Function):
@@ -134,6 +138,7 @@ class _chamfer_direction(Function):
         x, y, idx, xl, yl, w = ctx.saved_tensors[:6]
         x_feats = list(ctx.saved_tensors[6:6 + F_])
         y_feats = list(ctx.saved_tensors[6 + F_:6 + 2 * F_])
+        alert_not_deterministic("chamfer_distance backward")  # grad_y / grad_y_feats: fp32 atomics
         gx, gy, gxf, gyf = _C.chamfer_backward(x, y, idx.view(idx.shape[0], idx.shape[1]), xl, yl,
                                                w if ctx.has_w else None, grad_out.contiguous().float(), norm,
                                                x_feats, y_feats, abs_cosine, mean)
@@ -141,9 +146,9 @@ class _chamfer_direction(Function):
 
 
 def _fused_direction_ok(x, y, x_features, y_features, feature_names, return_features, point_reduction):
-    if point_reduction not in ("sum", "mean"):
-        return False
-    if not (x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32):
+    if point_reduction not in ("sum", "mean") or torch.compiler.is_compiling():
+        return False  # (traced graphs take the composed path over the registered ops)
+    if not (x.is_cuda and y.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32):
         return False
     if return_features:
         if len(feature_names) > _C.CHAMFER_MAX_FEATURES:
@@ -159,32 +164,45 @@ def _fused_direction_ok(x, y, x_features, y_features, feature_names, return_feat
     return True
 
 
-def _chamfer_distance_single_direction(
-    x,
-    y,
-    x_lengths,
-    y_lengths,
-    x_features,
-    y_features,
-    weights,
-    point_reduction: Union[str, None],
-    norm: int,
-    abs_cosine: bool,
-    feature_names: Union[list, None] = None,
-):
-    if feature_names and x_features is not None and y_features is not None:
-        for feature_name in feature_names:
-            if feature_name not in x_features:
-                raise ValueError(f"Feature '{feature_name}' is missing in x_features.")
-            if feature_name not in y_features:
-                raise ValueError(f"Feature '{feature_name}' is missing in y_features.")
+def _direction_composed(x, y, x_lengths, y_lengths, x_features, y_features, names, weights, point_reduction, norm,
+                        abs_cosine) -> _Terms:
+    """A direction out of knn_points / knn_gather / cosine_similarity and the fused masked reduction: every
+    reduction mode, any feature width."""
+    N, P1 = x.shape[:2]
+    nn = knn_points(x, y, lengths1=x_lengths, lengths2=y_lengths, norm=norm, K=1)
+    per_point = {"": nn.dists[..., 0]}  # (N, P1); rows >= x_lengths are already 0 (kernel padding)
+    for name in names:
+        nearest = knn_gather(y_features[name], nn.idx, y_lengths)[..., 0, :]
+        cos = F.cosine_similarity(x_features[name], nearest, dim=2, eps=1e-6)
+        per_point[name] = 1 - (cos.abs() if abs_cosine else cos)
 
-    return_features = (
-        x_features is not None
-        and y_features is not None
-        and feature_names is not None
-        and len(feature_names) > 0
-    )
+    if point_reduction in ("sum", "mean") and per_point[""].dtype == torch.float32 and not torch.compiler.is_compiling():
+        w32 = None if weights is None else weights.to(torch.float32)
+        done = {k: _masked_point_reduce.apply(v.contiguous(), x_lengths, w32, point_reduction == "mean")
+                for k, v in per_point.items()}
+    else:
+        outside = torch.arange(P1, device=x.device)[None] >= x_lengths[:, None]  # (N, P1) padding mask
+        done = {}
+        for k, v in per_point.items():
+            v = v.masked_fill(outside, 0.0)
+            done[k] = v if weights is None else v * weights.view(N, 1)
+        if point_reduction == "max":
+            assert not names
+            done[""] = done[""].max(1).values
+    return _Terms(done[""], {k: done[k] for k in names} if names else None)
+
+
+def _chamfer_distance_single_direction(x, y, x_lengths, y_lengths, x_features, y_features, weights,
+                                       point_reduction: Union[str, None], norm: int, abs_cosine: bool,
+                                       feature_names: Union[list, None] = None):
+    """(point term, feature terms or None) of the direction x -> y (reference: functions/chamfer.py:85-189)."""
+    have_both = x_features is not None and y_features is not None
+    if feature_names and have_both:
+        for name in feature_names:
+            for side, table in (("x_features", x_features), ("y_features", y_features)):
+                if name not in table:
+                    raise ValueError(f"Feature '{name}' is missing in {side}.")
+    names = list(feature_names) if (have_both and feature_names) else []
 
     N, P1, D = x.shape
     if y.shape[0] != N or y.shape[2] != D:
@@ -203,79 +221,57 @@ def _chamfer_distance_single_direction(
             zero = (x.sum((1, 2)) * weights) * 0.0  # (N,)
             if point_reduction is None:
                 zero = zero[:, None].expand(N, P1)
-            zf = {name: zero for name in feature_names} if return_features else None
-            return zero, zf
+            return _Terms(zero, {name: zero for name in names} if names else None)
 
-    if _fused_direction_ok(x, y, x_features, y_features, feature_names, return_features, point_reduction):
-        names = list(feature_names) if return_features else []
-        feats = [x_features[k] for k in names] + [y_features[k] for k in names]
-        out = _chamfer_direction.apply(x, y, x_lengths, y_lengths,
-                                       weights.to(torch.float32) if weights is not None else None, norm,
-                                       point_reduction == "mean", abs_cosine, *feats)
-        return out[0], ({k: out[1 + i] for i, k in enumerate(names)} if return_features else None)
+    if _fused_direction_ok(x, y, x_features, y_features, names, bool(names), point_reduction):
+        flat = [x_features[k] for k in names] + [y_features[k] for k in names]
+        rows = _chamfer_direction.apply(x, y, x_lengths, y_lengths,
+                                        None if weights is None else weights.to(torch.float32), norm,
+                                        point_reduction == "mean", abs_cosine, *flat)
+        return _Terms(rows[0], {k: rows[1 + i] for i, k in enumerate(names)} if names else None)
+    return _direction_composed(x, y, x_lengths, y_lengths, x_features, y_features, names, weights, point_reduction,
+                               norm, abs_cosine)
 
-    x_nn = knn_points(x, y, lengths1=x_lengths, lengths2=y_lengths, norm=norm, K=1)
-    cham_x = x_nn.dists[..., 0]  # (N, P1); rows >= x_lengths are already 0 (kernel padding)
 
-    fused = point_reduction in ("sum", "mean") and cham_x.dtype == torch.float32
-    w32 = None
-    if weights is not None:
-        w32 = weights.to(torch.float32)
-
-    cham_features_x = None
-    if not fused:
-        x_mask = torch.arange(P1, device=x.device)[None] >= x_lengths[:, None]  # (N, P1)
-        cham_x = cham_x.masked_fill(x_mask, 0.0)
-        if weights is not None:
-            cham_x = cham_x * weights.view(N, 1)
-
-    if return_features:
-        cham_features_x = {}
-        for feature_name in feature_names:
-            x_feature = x_features[feature_name]
-            y_feature = y_features[feature_name]
-            x_feature_near = knn_gather(y_feature, x_nn.idx, y_lengths)[..., 0, :]
-            cosine_sim = F.cosine_similarity(x_feature, x_feature_near, dim=2, eps=1e-6)
-            cosine_sim = torch.abs(cosine_sim) if abs_cosine else cosine_sim
-            feature_distance = 1 - cosine_sim  # (N, P1)
-            if fused:
-                cham_features_x[feature_name] = _masked_point_reduce.apply(
-                    feature_distance.contiguous(), x_lengths, w32, point_reduction == "mean")
-            else:
-                feature_distance = feature_distance.masked_fill(x_mask, 0.0)
-                if weights is not None:
-                    feature_distance = feature_distance * weights.view(N, 1)
-                cham_features_x[feature_name] = feature_distance
-
+def _combine(fwd: _Terms, bwd: _Terms, point_reduction: Union[str, None]) -> _Terms:
+    """Both directions into one result (reference: functions/chamfer.py:316-354): elementwise maximum for
+    "max" (no feature loss), sum for "sum" / "mean", the (x, y) pair when there is no point reduction.  A feature
+    the reverse direction lacks keeps the forward term (paired with None)."""
     if point_reduction == "max":
-        assert not return_features
-        cham_x = cham_x.max(1).values  # (N,)
-    elif fused:
-        cham_x = _masked_point_reduce.apply(cham_x.contiguous(), x_lengths, w32,
-                                            point_reduction == "mean")
-    return cham_x, cham_features_x
+        return _Terms(torch.maximum(fwd.points, bwd.points), None)
+    if point_reduction is not None:
+        def join(a, b):
+            return a if b is None else a + b
+    else:
+        def join(a, b):
+            return (a, b)
+    feats = None
+    if fwd.feats is not None:
+        other = bwd.feats or {}
+        feats = {k: join(v, other.get(k)) for k, v in fwd.feats.items()}
+    return _Terms(join(fwd.points, bwd.points), feats)
+
+
+def _reduce_batch(terms: _Terms, weights, batch_reduction: Union[str, None]) -> _Terms:
+    """Batch reduction of every term (reference: functions/chamfer.py:192-214): sum over clouds, and for
+    "mean" a division by the weight sum (cloud count without weights; 1 when the weights sum to zero)."""
+    if batch_reduction is None:
+        return terms
+    n_clouds = terms.points.shape[0]
+    terms = terms.map(torch.sum)
+    if batch_reduction == "sum":
+        return terms
+    if weights is None:
+        denom = max(n_clouds, 1)
+    else:
+        total = weights.sum()
+        denom = 1 if total == 0.0 else total
+    return terms.map(lambda t: t / denom)
 
 
 def _apply_batch_reduction(cham_x, cham_features_x, weights, batch_reduction: Union[str, None]):
-    if batch_reduction is None:
-        return (cham_x, cham_features_x)
-    N = cham_x.shape[0]
-    cham_x = cham_x.sum()
-    if cham_features_x is not None:
-        for feature_name in cham_features_x:
-            cham_features_x[feature_name] = cham_features_x[feature_name].sum()
-    if batch_reduction == "mean":
-        if weights is None:
-            div = max(N, 1)
-        elif weights.sum() == 0.0:
-            div = 1
-        else:
-            div = weights.sum()
-        cham_x = cham_x / div
-        if cham_features_x is not None:
-            for feature_name in cham_features_x:
-                cham_features_x[feature_name] = cham_features_x[feature_name] / div
-    return (cham_x, cham_features_x)
+    """Tuple form of `_reduce_batch` under the reference's helper name (functions/chamfer.py:192)."""
+    return tuple(_reduce_batch(_Terms(cham_x, cham_features_x), weights, batch_reduction))
 
 
 def chamfer_distance(
@@ -299,56 +295,19 @@ def chamfer_distance(
     Pointclouds-like objects; ``loss_features`` is None or a dict per feature name.
     """
     _validate_chamfer_reduction_inputs(batch_reduction, point_reduction)
-
-    if not ((norm == 1) or (norm == 2)):
+    if norm not in (1, 2):
         raise ValueError("Support for 1 or 2 norm.")
-
-    if point_reduction == "max" and (feature_names is not None and len(feature_names) > 0):
+    if point_reduction == "max" and feature_names:
         raise ValueError('Features must be None if point_reduction is "max"')
 
     x, x_lengths, x_features = _handle_pointcloud_input(x, x_lengths, x_features)
     y, y_lengths, y_features = _handle_pointcloud_input(y, y_lengths, y_features)
 
-    cham_x, cham_features_x = _chamfer_distance_single_direction(
-        x, y, x_lengths, y_lengths, x_features, y_features, weights, point_reduction, norm,
-        abs_cosine, feature_names,
-    )
-    if single_directional:
-        loss = cham_x
-        loss_features = cham_features_x
-    else:
-        cham_y, cham_features_y = _chamfer_distance_single_direction(
-            y, x, y_lengths, x_lengths, y_features, x_features, weights, point_reduction, norm,
-            abs_cosine, feature_names,
-        )
-        if point_reduction == "max":
-            loss = torch.maximum(cham_x, cham_y)
-            loss_features = None
-        elif point_reduction is not None:
-            loss = cham_x + cham_y
-            if cham_features_x is not None:
-                loss_features = {}
-                for feature_name in cham_features_x:
-                    if feature_name in cham_features_y:
-                        loss_features[feature_name] = (
-                            cham_features_x[feature_name] + cham_features_y[feature_name]
-                        )
-                    else:
-                        loss_features[feature_name] = cham_features_x[feature_name]
-            else:
-                loss_features = None
-        else:
-            loss = (cham_x, cham_y)
-            if cham_features_x is not None:
-                loss_features = {}
-                for feature_name in cham_features_x:
-                    if feature_name in cham_features_y:
-                        loss_features[feature_name] = (
-                            cham_features_x[feature_name],
-                            cham_features_y[feature_name],
-                        )
-                    else:
-                        loss_features[feature_name] = (cham_features_x[feature_name], None)
-            else:
-                loss_features = None
-    return _apply_batch_reduction(loss, loss_features, weights, batch_reduction)
+    def direction(a, b, a_len, b_len, a_feat, b_feat):
+        return _chamfer_distance_single_direction(a, b, a_len, b_len, a_feat, b_feat, weights, point_reduction, norm,
+                                                  abs_cosine, feature_names)
+
+    terms = direction(x, y, x_lengths, y_lengths, x_features, y_features)
+    if not single_directional:
+        terms = _combine(terms, direction(y, x, y_lengths, x_lengths, y_features, x_features), point_reduction)
+    return tuple(_reduce_batch(terms, weights, batch_reduction))

@@ -11,23 +11,9 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
+from ._common import alert_not_deterministic, as_f32, full_lengths, neighbor_backward, point_pair
 
 _KNN = namedtuple("KNN", "dists idx knn")
-
-_full_lengths_cache = {}
-
-
-def _full_lengths(n: int, p: int, device) -> torch.Tensor:
-    """(n,) int64 tensor filled with p: the default `lengths` (reference: functions/knn.py:184-187).
-    Read-only for the kernels, so one cached tensor per (n, p, device) saves a fill launch per call."""
-    key = (n, p, device)
-    t = _full_lengths_cache.get(key)
-    if t is None:
-        if len(_full_lengths_cache) > 64:
-            _full_lengths_cache.clear()
-        t = torch.full((n,), p, dtype=torch.int64, device=device)
-        _full_lengths_cache[key] = t
-    return t
 
 
 class _knn_points(Function):
@@ -54,15 +40,9 @@ class _knn_points(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_dists, grad_idx):
-        p1, p2, lengths1, lengths2, idx = ctx.saved_tensors
-        norm = ctx.norm
-        if not (grad_dists.dtype == torch.float32):
-            grad_dists = grad_dists.float()
-        if not (p1.dtype == torch.float32):
-            p1 = p1.float()
-        if not (p2.dtype == torch.float32):
-            p2 = p2.float()
-        grad_p1, grad_p2 = _C.knn_points_backward(p1, p2, lengths1, lengths2, idx, norm, grad_dists)
+        # grad_p2 is a scatter-add with fp32 atomics: the reference's CUDA backward raises the same
+        # nondeterminism alert (csrc/knn/knn.cu:538)
+        grad_p1, grad_p2 = neighbor_backward(ctx.saved_tensors, ctx.norm, grad_dists, "knn_points backward")
         return grad_p1, grad_p2, None, None, None, None, None, None
 
 
@@ -85,28 +65,14 @@ def knn_points(
     knn (N,P1,K,D) or None)``; dists/idx are zero for rows >= lengths1[n] and
     slots >= lengths2[n].
     """
-    if p1.shape[0] != p2.shape[0]:
-        raise ValueError("pts1 and pts2 must have the same batch dimension.")
-    if p1.shape[2] != p2.shape[2]:
-        raise ValueError("pts1 and pts2 must have the same point dimension.")
-
-    p1 = p1.contiguous()
-    p2 = p2.contiguous()
-    P1 = p1.shape[1]
-    P2 = p2.shape[1]
-
-    if lengths1 is None:
-        lengths1 = _full_lengths(p1.shape[0], P1, p1.device)
-    if lengths2 is None:
-        lengths2 = _full_lengths(p1.shape[0], P2, p1.device)
-
-    p1_dists, p1_idx = _knn_points.apply(p1, p2, lengths1, lengths2, K, version, norm, return_sorted)
-
-    p2_nn = None
-    if return_nn:
-        p2_nn = knn_gather(p2, p1_idx, lengths2)
-
-    return _KNN(dists=p1_dists, idx=p1_idx, knn=p2_nn if return_nn else None)
+    p1, p2, lengths1, lengths2 = point_pair(p1, p2, lengths1, lengths2)
+    if torch.compiler.is_compiling():  # a graph is being traced: the registered op (pytorch3d_pointops_amd/ops.py)
+        if norm not in (1, 2):
+            raise ValueError("Support for 1 or 2 norm.")
+        idx, dists = torch.ops.pointops_amd.knn_points_idx(p1, p2, lengths1, lengths2, norm, K, version)
+    else:
+        dists, idx = _knn_points.apply(p1, p2, lengths1, lengths2, K, version, norm, return_sorted)
+    return _KNN(dists=dists, idx=idx, knn=knn_gather(p2, idx, lengths2) if return_nn else None)
 
 
 class _gather_neighbors(Function):
@@ -125,9 +91,8 @@ class _gather_neighbors(Function):
     @once_differentiable
     def backward(ctx, grad_out):
         idx, lengths = ctx.saved_tensors
-        if not (grad_out.dtype == torch.float32):
-            grad_out = grad_out.float()
-        grad_x = _C.gather_neighbors_backward(grad_out.contiguous(), idx,
+        alert_not_deterministic("knn_gather backward")  # fp32 scatter-add (LDS or device atomics)
+        grad_x = _C.gather_neighbors_backward(as_f32(grad_out).contiguous(), idx,
                                               lengths if ctx.has_lengths else None, ctx.M)
         return grad_x, None, None
 
@@ -147,6 +112,8 @@ def knn_gather(x: torch.Tensor, idx: torch.Tensor, lengths: Union[torch.Tensor, 
     if x.dtype != torch.float32:
         # rare path (the reference gathers any dtype): same semantics through torch
         return _knn_gather_torch(x, idx, lengths)
+    if torch.compiler.is_compiling():
+        return torch.ops.pointops_amd.gather_neighbors(x, idx, lengths)
     return _gather_neighbors.apply(x, idx, lengths)
 
 

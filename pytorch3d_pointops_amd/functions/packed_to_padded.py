@@ -48,7 +48,10 @@ def packed_to_padded(inputs: torch.Tensor, first_idxs: torch.LongTensor, max_siz
     packed rows from first_idxs[i] up to first_idxs[i+1] (the last one up to F).  Differentiable."""
     trailing = tuple(inputs.shape[1:])
     flat = inputs.reshape(inputs.shape[0], -1) if trailing else inputs[:, None]
-    padded = _RaggedCopyFn.apply(flat, first_idxs, max_size, True)
+    if torch.compiler.is_compiling():
+        padded = torch.ops.pointops_amd.packed_to_padded(flat.contiguous(), first_idxs.contiguous(), max_size)
+    else:
+        padded = _RaggedCopyFn.apply(flat, first_idxs, max_size, True)
     return padded.reshape(padded.shape[0], padded.shape[1], *trailing)
 
 
@@ -63,5 +66,8 @@ def padded_to_packed(
     moved = inputs.movedim(max_size_dim, 1)
     trailing = tuple(moved.shape[2:])
     flat = moved.reshape(moved.shape[0], moved.shape[1], -1) if trailing else moved[:, :, None]
-    packed = _RaggedCopyFn.apply(flat, first_idxs, num_inputs, False)
+    if torch.compiler.is_compiling():
+        packed = torch.ops.pointops_amd.padded_to_packed(flat.contiguous(), first_idxs.contiguous(), num_inputs)
+    else:
+        packed = _RaggedCopyFn.apply(flat, first_idxs, num_inputs, False)
     return packed.reshape(packed.shape[0], *trailing)

@@ -62,7 +62,10 @@ def sample_farthest_points(
             start_idxs[n] = torch.randint(high=lengths[n], size=(1,)).item()
 
     with torch.no_grad():
-        idx = _C.sample_farthest_points(points, lengths, K, start_idxs)
+        if torch.compiler.is_compiling():
+            idx = torch.ops.pointops_amd.sample_farthest_points(points, lengths, K, start_idxs)
+        else:
+            idx = _C.sample_farthest_points(points, lengths, K, start_idxs)
     sampled_points = masked_gather(points, idx)
     return sampled_points, idx
 

@@ -21,16 +21,16 @@ def masked_gather(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
     if len(idx) != len(points):
         raise ValueError("points and idx must have the same batch dimension")
-    if idx.ndim == 3:
-        if points.dtype != torch.float32:
-            return _masked_gather_torch(points, idx)
-        return _gather_neighbors.apply(points, idx, None)
-    elif idx.ndim == 2:
-        if points.dtype != torch.float32:
-            return _masked_gather_torch(points, idx)
-        return _gather_neighbors.apply(points, idx[:, :, None], None)[:, :, 0, :]
-    else:
+    if idx.ndim not in (2, 3):
         raise ValueError("idx format is not supported %s" % repr(idx.shape))
+    if points.dtype != torch.float32:
+        return _masked_gather_torch(points, idx)
+    table = idx if idx.ndim == 3 else idx[:, :, None]
+    if torch.compiler.is_compiling():
+        out = torch.ops.pointops_amd.gather_neighbors(points, table.contiguous(), None)
+    else:
+        out = _gather_neighbors.apply(points, table, None)
+    return out if idx.ndim == 3 else out[:, :, 0, :]
 
 
 def _masked_gather_torch(points, idx):
@@ -80,6 +80,8 @@ def get_point_covariances(
     if (k_nearest_neighbors.is_cuda and k_nearest_neighbors.dtype == torch.float32
             and 1 <= k_nearest_neighbors.shape[3] <= _C.POINT_COVARIANCES_MAX_D and k_nearest_neighbors.shape[2] >= 1):
         # fused: no (N,P,K,D,D) tensor of outer products, closed-form backward (csrc/covariance.hip)
+        if torch.compiler.is_compiling():
+            return torch.ops.pointops_amd.point_covariances(k_nearest_neighbors.contiguous()), k_nearest_neighbors
         return _point_covariances.apply(k_nearest_neighbors), k_nearest_neighbors
     pt_mean = k_nearest_neighbors.mean(2, keepdim=True)
     central_diff = k_nearest_neighbors - pt_mean

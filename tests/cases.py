@@ -185,3 +185,24 @@ def sample_pdf_cases():
         u[0, -1] = 1.0
         c[name] = dict(bins=bins, weights=w, u=u, eps=1e-5)
     return c
+
+
+# ---------------------------------------------------------------- the reference's example script
+def example_clouds():
+    """Clouds shaped like examples/knn_on_pointclouds.py:15-58 of the reference: a 1500-point sphere shell
+    (radius 0.2..1) and an 800-point ellipsoid shell (radius 0.4..1, x stretched 1.5, y squeezed 0.8), unit
+    normals and random colours.  (make_golden.py stores these arrays in the fixture; tests read them back.)"""
+    def shell(seed, n, r0, r1, sx, sy):
+        u = synth.uniform_f32(seed, (n, 3)).astype(np.float64)
+        theta, phi, r = u[:, 0] * 2 * np.pi, u[:, 1] * np.pi, u[:, 2] * (r1 - r0) + r0
+        return np.stack([r * np.sin(phi) * np.cos(theta) * sx, r * np.sin(phi) * np.sin(theta) * sy,
+                         r * np.cos(phi)], axis=1).astype(np.float32)
+
+    def unit(a):
+        a = a.astype(np.float64)
+        return (a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-12)).astype(np.float32)
+
+    p0, p1 = shell(901, 1500, 0.2, 1.0, 1.0, 1.0), shell(902, 800, 0.4, 1.0, 1.5, 0.8)
+    n1 = unit(p1 / np.array([2.25, 0.64, 1.0]))
+    return dict(points=[p0, p1], normals=[unit(p0), n1],
+                colors=[synth.uniform_f32(903, (1500, 3)), synth.uniform_f32(904, (800, 3))])

@@ -258,6 +258,39 @@ def gen_sample_pdf():
     save("sample_pdf", **out)
 
 
+def gen_examples():
+    """The call patterns of the reference's own examples/knn_on_pointclouds.py (:24,35,78-88,130-190) at its
+    sizes: a Pointclouds batch of a 1500-point sphere shell and an 800-point ellipsoid shell with "normals"
+    and "colors" features; self-KNN K=10 on the padded batch with per-cloud lengths, a 200 x 800 cross query
+    K=5, knn_gather of normals / colors through the neighbour table, inverse-distance interpolation.  The
+    script draws its clouds from torch.rand; the fixture stores the (synth-generated) inputs next to the
+    reference's outputs so that nothing depends on an RNG or a libm."""
+    from pytorch3d_pointops.structures import Pointclouds as RefPointclouds
+
+    inp = cases.example_clouds()
+    pc = RefPointclouds(points=[T(a) for a in inp["points"]],
+                        features={"normals": [T(a) for a in inp["normals"]], "colors": [T(a) for a in inp["colors"]]})
+    out = {f"in/points{i}": a for i, a in enumerate(inp["points"])}
+    out.update({f"in/normals{i}": a for i, a in enumerate(inp["normals"])})
+    out.update({f"in/colors{i}": a for i, a in enumerate(inp["colors"])})
+    padded, lens = pc.points_padded(), pc.num_points_per_cloud()
+    out["self/padded"] = padded.numpy()
+    r = knn_points(padded, padded, lengths1=lens, lengths2=lens, K=10, return_nn=True)  # :81-88
+    out["self/dists"], out["self/idx"], out["self/knn"] = r.dists.numpy(), r.idx.numpy().astype(np.int32), r.knn.numpy()
+    q = T(inp["points"][0][:200])[None]  # :130-149
+    t = T(inp["points"][1])[None]
+    c = knn_points(p1=q, p2=t, K=5, return_nn=False)
+    out["cross/dists"], out["cross/idx"] = c.dists.numpy(), c.idx.numpy().astype(np.int32)
+    gn = knn_gather(T(inp["normals"][1])[None], c.idx)[0]  # :155-156
+    gc = knn_gather(T(inp["colors"][1])[None], c.idx)[0]
+    out["cross/gathered_normals"], out["cross/gathered_colors"] = gn.numpy(), gc.numpy()
+    w = 1.0 / (torch.sqrt(c.dists[0]) + 1e-8)  # :165-178
+    w = w / w.sum(dim=1, keepdim=True)
+    out["cross/interp_normals"] = torch.nn.functional.normalize((gn * w.unsqueeze(-1)).sum(dim=1), p=2, dim=1).numpy()
+    out["cross/interp_colors"] = (gc * w.unsqueeze(-1)).sum(dim=1).numpy()
+    save("examples", **out)
+
+
 def gen_big():
     """cfg2-size single clouds: digests + sampled rows (the full idx would be 8 MB per cloud)."""
     meta = {}
@@ -309,5 +342,6 @@ if __name__ == "__main__":
     gen_chamfer()
     gen_sample_pdf()
     gen_covariances()
+    gen_examples()
     if "--big" in sys.argv:
         gen_big()

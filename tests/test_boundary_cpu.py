@@ -96,21 +96,27 @@ def test_fps_validation_errors():
 
 
 def test_packed_validation_errors():
-    from pytorch3d_pointops_amd.functions.packed_to_padded import _PackedToPadded, _PaddedToPacked
+    from pytorch3d_pointops_amd.functions.packed_to_padded import _RaggedCopyFn, packed_to_padded, padded_to_packed
 
     f = torch.tensor([0, 2])
-    with pytest.raises(ValueError, match="2-dimensional"):
-        _PackedToPadded.apply(torch.rand(4), f, 2)
-    with pytest.raises(ValueError, match="1-dimensional"):
-        _PackedToPadded.apply(torch.rand(4, 3), f[None], 2)
+    # the reference's texts (functions/packed_to_padded.py:38-47, :130-139), raised by the shared autograd node
+    with pytest.raises(ValueError, match="input can only be 2-dimensional."):
+        _RaggedCopyFn.apply(torch.rand(4), f, 2, True)
+    with pytest.raises(ValueError, match="first_idxs can only be 1-dimensional."):
+        _RaggedCopyFn.apply(torch.rand(4, 3), f[None], 2, True)
+    with pytest.raises(ValueError, match="input has to be of type torch.float32."):
+        _RaggedCopyFn.apply(torch.rand(4, 3).double(), f, 2, True)
+    with pytest.raises(ValueError, match="first_idxs has to be of type torch.int64."):
+        _RaggedCopyFn.apply(torch.rand(4, 3), f.int(), 2, True)
+    with pytest.raises(ValueError, match="max_size has to be int."):
+        _RaggedCopyFn.apply(torch.rand(4, 3), f, 2.0, True)
+    with pytest.raises(ValueError, match="input can only be 3-dimensional."):
+        _RaggedCopyFn.apply(torch.rand(4, 3), f, 4, False)
+    # and through the public wrappers
     with pytest.raises(ValueError, match="float32"):
-        _PackedToPadded.apply(torch.rand(4, 3).double(), f, 2)
+        packed_to_padded(torch.rand(4, 3).double(), f, 2)
     with pytest.raises(ValueError, match="int64"):
-        _PackedToPadded.apply(torch.rand(4, 3), f.int(), 2)
-    with pytest.raises(ValueError, match="has to be int"):
-        _PackedToPadded.apply(torch.rand(4, 3), f, 2.0)
-    with pytest.raises(ValueError, match="3-dimensional"):
-        _PaddedToPacked.apply(torch.rand(4, 3), f, 4)
+        padded_to_packed(torch.rand(2, 2, 3), f.int(), 4)
 
 
 def test_chamfer_validation_errors():

@@ -858,3 +858,234 @@ def test_sample_pdf_wrapper(dev):
         sample_pdf(bins[..., :-1], w, 4)
     with pytest.raises(NotImplementedError):
         sample_pdf(bins, w.clone().requires_grad_(True), 4)
+
+
+# ------------------------------------------------------------------ round 2: launch shapes that had no parity check
+def test_cfg3_fps_full_batch(dev, monkeypatch):
+    """BASELINE.json configs[2] FPS half at full size (B=16, N=131072 -> 1024): the batched launch (16 clouds x
+    16 workgroups = every CU, XCD-local clusters, per-iteration slot exchange) gives, for EVERY cloud, the
+    indices of that cloud sampled alone; cloud 0 is the cloud whose reference output is pinned in
+    tests/golden/big.npz.  Repeated for every cluster placement mode and with the exchange forced to time
+    out (fps_spin_limit=0: all clouds are then redone by the single-workgroup repair pass)."""
+    from pytorch3d_pointops_amd import _C
+
+    meta = json.load(open(os.path.join(GOLDEN, "big_meta.json")))["cfg3_fps"]
+    g = load_golden("big")
+    B, P, K = 16, meta["P"], meta["K"]
+    pts = np.empty((B, P, 3), np.float32)
+    for b in range(B):
+        pts[b] = cases.cloud(meta["seed"] + 10 * b, (P, 3))
+    x = G(pts, dev)
+    full = lambda n, v: torch.full((n,), v, dtype=torch.int64, device=dev)
+    alone = torch.cat([_C.sample_farthest_points(x[b:b + 1], full(1, P), full(1, K), full(1, 0)) for b in range(B)])
+    assert np.array_equal(alone[0].cpu().numpy(), g["cfg3_fps/idx"][0].astype(np.int64))
+    for knobs in ("fps_mode=2", "fps_mode=1", "fps_mode=0", "fps_spin_limit=0"):
+        monkeypatch.setenv("POINTOPS_DEBUG", knobs)
+        batch = _C.sample_farthest_points(x, full(B, P), full(B, K), full(B, 0))
+        assert torch.equal(batch, alone), knobs
+    # ragged batch through the same launch: per-cloud lengths and K, start indices != 0
+    monkeypatch.delenv("POINTOPS_DEBUG")
+    lens = torch.tensor([P, 70000, 1, 131071] * 4, dtype=torch.int64, device=dev)
+    ks = torch.tensor([K, 5, 3, 700] * 4, dtype=torch.int64, device=dev)
+    st = torch.tensor([0, 69999, 0, 12345] * 4, dtype=torch.int64, device=dev)
+    batch = _C.sample_farthest_points(x, lens, ks, st)
+    for b in (1, 2, 3, 7):
+        one = _C.sample_farthest_points(x[b:b + 1], lens[b:b + 1], ks[b:b + 1], st[b:b + 1])
+        assert torch.equal(batch[b, : one.shape[1]], one[0]) and bool((batch[b, one.shape[1]:] == -1).all())
+
+
+def test_cfg4_ragged_knn_vs_bruteforce_sample(dev):
+    """BASELINE.json configs[3] shape (B=8, ragged 20k..200k): both K=1 searches of the chamfer at full size,
+    sampled queries of every cloud against a brute-force torch distance row over the cloud's valid points
+    (nearest index with ties to the lowest index, bit-equal distance); padded rows are zero."""
+    from pytorch3d_pointops_amd import synth
+    from pytorch3d_pointops_amd.functions import knn_points
+
+    Bq = 8
+    l1 = synth.randint(41, 20000, 200000, (Bq,))
+    l2 = synth.randint(42, 20000, 200000, (Bq,))
+    P1, P2 = int(l1.max()), int(l2.max())
+    x, y = G(synth.uniform_f32(43, (Bq, P1, 3)), dev), G(synth.uniform_f32(44, (Bq, P2, 3)), dev)
+    for a, b, la, lb in ((x, y, l1, l2), (y, x, l2, l1)):
+        r = knn_points(a, b, G(la, dev), G(lb, dev), K=1)
+        for n in range(Bq):
+            qs = torch.arange(3, int(la[n]), 997, device=dev)
+            dq = a[n, qs][:, None, :] - b[n, : int(lb[n])][None, :, :]
+            dq = dq * dq
+            full = (dq[..., 0] + dq[..., 1]) + dq[..., 2]
+            best = full.min(1)
+            first = torch.where(full == best.values[:, None], torch.arange(full.shape[1], device=dev)[None],
+                                full.shape[1]).min(1).values
+            assert torch.equal(r.idx[n, qs, 0], first) and torch.equal(r.dists[n, qs, 0], best.values), n
+            assert bool((r.idx[n, int(la[n]):] == 0).all()) and bool((r.dists[n, int(la[n]):] == 0).all())
+
+
+def test_cfg5_rank_workload_sharded_chamfer_nccl(dev):
+    """BASELINE.json configs[4], one rank's share (32 clouds x 65536 points, fwd + bwd) through
+    `sharded_chamfer_distance` on the `nccl` (RCCL) backend with world_size 1 -- the all_gather, its
+    backward and the batch reduction on the real backend -- against chamfer_distance(batch_reduction="mean")
+    on the same clouds: loss equal, gradients equal up to atomic order."""
+    import torch.distributed as dist
+
+    from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance
+    from pytorch3d_pointops_amd.sharded import sharded_chamfer_distance
+
+    B, P = 32, 65536
+    p1 = np.empty((B, P, 3), np.float32)
+    p2 = np.empty((B, P, 3), np.float32)
+    for b in range(B):
+        p1[b] = cases.cloud(7001 + 10 * b, (P, 3))
+        p2[b] = cases.cloud(7002 + 10 * b, (P, 3))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    started = not dist.is_initialized()
+    if started:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        xa, ya = G(p1, dev).requires_grad_(True), G(p2, dev).requires_grad_(True)
+        xb, yb = G(p1, dev).requires_grad_(True), G(p2, dev).requires_grad_(True)
+        ls, _ = sharded_chamfer_distance(xa, ya, B)
+        ls.backward()
+        lr, _ = chamfer_distance(xb, yb, batch_reduction="mean")
+        lr.backward()
+        assert abs(float(ls) - float(lr)) <= 1e-6 * max(1.0, abs(float(lr)))
+        assert close(xa.grad.cpu().numpy(), xb.grad.cpu().numpy()) and close(ya.grad.cpu().numpy(), yb.grad.cpu().numpy())
+        per, _ = sharded_chamfer_distance(xa.detach(), ya.detach(), B, batch_reduction=None)
+        assert per.shape == (B,) and abs(float(per.mean()) - float(lr)) <= 1e-6
+    finally:
+        if started:
+            dist.destroy_process_group()
+
+
+def test_reference_example_call_patterns(dev):
+    """The reference's own example script (examples/knn_on_pointclouds.py) at its sizes: Pointclouds batch of
+    1500 + 800 points, self-KNN K=10 with per-cloud lengths, 200 x 800 cross query K=5, knn_gather of normals /
+    colours and the inverse-distance interpolation -- against what the reference produced on these inputs
+    (tests/golden/examples.npz, inputs stored in the fixture)."""
+    from pytorch3d_pointops_amd.functions import knn_gather, knn_points
+    from pytorch3d_pointops_amd.structures import Pointclouds
+
+    g = load_golden("examples")
+    pts = [G(g[f"in/points{i}"], dev) for i in range(2)]
+    nrm = [G(g[f"in/normals{i}"], dev) for i in range(2)]
+    col = [G(g[f"in/colors{i}"], dev) for i in range(2)]
+    pc = Pointclouds(points=pts, features={"normals": nrm, "colors": col})
+    padded, lens = pc.points_padded(), pc.num_points_per_cloud()
+    assert np.array_equal(padded.cpu().numpy(), g["self/padded"])
+    r = knn_points(padded, padded, lengths1=lens, lengths2=lens, K=10, return_nn=True)
+    assert np.array_equal(r.idx.cpu().numpy(), g["self/idx"].astype(np.int64))
+    assert np.array_equal(bits(r.dists.cpu().numpy()), bits(g["self/dists"]))
+    assert np.array_equal(bits(r.knn.cpu().numpy()), bits(g["self/knn"]))
+    c = knn_points(p1=pts[0][:200][None], p2=pts[1][None], K=5, return_nn=False)
+    assert np.array_equal(c.idx.cpu().numpy(), g["cross/idx"].astype(np.int64))
+    assert np.array_equal(bits(c.dists.cpu().numpy()), bits(g["cross/dists"]))
+    gn = knn_gather(nrm[1][None], c.idx)[0]
+    gc = knn_gather(col[1][None], c.idx)[0]
+    assert np.array_equal(bits(gn.cpu().numpy()), bits(g["cross/gathered_normals"]))
+    assert np.array_equal(bits(gc.cpu().numpy()), bits(g["cross/gathered_colors"]))
+    w = 1.0 / (torch.sqrt(c.dists[0]) + 1e-8)
+    w = w / w.sum(dim=1, keepdim=True)
+    interp_n = torch.nn.functional.normalize((gn * w.unsqueeze(-1)).sum(dim=1), p=2, dim=1)
+    assert close(interp_n.cpu().numpy(), g["cross/interp_normals"]) and close(
+        (gc * w.unsqueeze(-1)).sum(dim=1).cpu().numpy(), g["cross/interp_colors"])
+
+
+def test_self_query_reuses_point_sort_cfg1_pattern(dev, oracle, monkeypatch):
+    """cfg1 call pattern (knn_points(p, p): the same tensor twice) at a size the grid takes: identical to the
+    p1 != p2 machinery and to the oracle; also through ball_query and get_point_covariances."""
+    from pytorch3d_pointops_amd.functions import ball_query, knn_points
+
+    p = cases.cloud(2101, (3, 9000, 3))
+    p[1] = (p[1] ** np.float32(3.0)).astype(np.float32)
+    lens = np.array([9000, 4321, 17])
+    t, lt = G(p, dev), G(lens, dev)
+    r = knn_points(t, t, lt, lt, K=16, version=3)
+    oi, od = oracle.knn_points_idx(p, p, lens, lens, 2, 16)
+    assert np.array_equal(r.idx.cpu().numpy(), oi) and np.array_equal(bits(r.dists.cpu().numpy()), bits(od))
+    monkeypatch.setenv("POINTOPS_DEBUG", "ball_grid=1,ball_factor=0")
+    b = ball_query(t, t, lt, lt, K=12, radius=0.05, return_nn=False)
+    bi, bd = oracle.ball_query(p, p, lens, lens, 12, 0.05)
+    assert np.array_equal(b.idx.cpu().numpy(), bi) and np.array_equal(bits(b.dists.cpu().numpy()), bits(bd))
+
+
+def test_registered_ops_and_torch_compile(dev):
+    """The operators are registered torch ops (torch.ops.pointops_amd.*) with fake implementations and autograd:
+    `torch.compile(knn_points)` traces through them and returns what the eager call returns -- values and
+    gradients; opcheck-style: the op list covers the `_C` operator boundary."""
+    from pytorch3d_pointops_amd import ops
+    from pytorch3d_pointops_amd.functions import knn_gather, knn_points
+
+    need = {"knn_points_idx", "knn_points_backward", "ball_query", "sample_farthest_points", "packed_to_padded",
+            "padded_to_packed", "gather_neighbors", "gather_neighbors_backward", "sample_pdf"}
+    assert need <= set(ops.registered_ops())
+    p1 = G(cases.cloud(2201, (2, 700, 3)), dev)
+    p2 = G(cases.cloud(2202, (2, 900, 3)), dev)
+    feats = G(cases.cloud(2203, (2, 900, 5)), dev)
+    l1, l2 = G(np.array([700, 301]), dev), G(np.array([900, 555]), dev)
+
+    def fn(a, b, f):
+        r = knn_points(a, b, l1, l2, K=6, return_nn=True)
+        return r.dists, r.idx, r.knn, knn_gather(f, r.idx, l2)
+
+    a1, b1, f1 = (t.clone().requires_grad_(True) for t in (p1, p2, feats))
+    e = fn(a1, b1, f1)
+    (e[0].sum() + (e[2] * 0.5).sum() + e[3].sum()).backward()
+    a2, b2, f2 = (t.clone().requires_grad_(True) for t in (p1, p2, feats))
+    c = torch.compile(fn, fullgraph=True)(a2, b2, f2)
+    (c[0].sum() + (c[2] * 0.5).sum() + c[3].sum()).backward()
+    for u, v in zip(e, c):
+        assert torch.equal(u, v)
+    assert torch.equal(a1.grad, a2.grad) and close(b1.grad.cpu().numpy(), b2.grad.cpu().numpy())
+    assert close(f1.grad.cpu().numpy(), f2.grad.cpu().numpy())
+    # the raw op is differentiable on its own as well
+    a3 = p1.clone().requires_grad_(True)
+    idx, d = torch.ops.pointops_amd.knn_points_idx(a3, p2, l1, l2, 2, 6, -1)
+    d.sum().backward()
+    assert torch.equal(idx, e[1]) and torch.equal(a3.grad, torch.autograd.grad(fn(a1, b1, f1)[0].sum(), a1)[0])
+
+
+def test_deterministic_algorithms_alert(dev):
+    """The scatter-add backward passes (fp32 atomics) raise the alert the reference's CUDA backward raises
+    (csrc/knn/knn.cu:538 alertNotDeterministic) under torch.use_deterministic_algorithms(True), warn with
+    warn_only=True, and the forward passes (deterministic) are unaffected."""
+    from pytorch3d_pointops_amd.functions import knn_gather, knn_points
+    from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance
+
+    a = G(cases.cloud(2301, (2, 300, 3)), dev).requires_grad_(True)
+    b = G(cases.cloud(2302, (2, 400, 3)), dev).requires_grad_(True)
+    try:
+        torch.use_deterministic_algorithms(True)
+        r = knn_points(a, b, K=4)  # forward: fine
+        with pytest.raises(RuntimeError, match="does not have a deterministic implementation"):
+            r.dists.sum().backward()
+        with pytest.raises(RuntimeError, match="does not have a deterministic implementation"):
+            knn_gather(b, r.idx).sum().backward()
+        loss, _ = chamfer_distance(a, b)
+        with pytest.raises(RuntimeError, match="does not have a deterministic implementation"):
+            loss.backward()
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        with pytest.warns(UserWarning, match="does not have a deterministic implementation"):
+            knn_points(a, b, K=4).dists.sum().backward()
+    finally:
+        torch.use_deterministic_algorithms(False)
+    assert a.grad is not None
+
+
+def test_chamfer_device_and_layout_checks(dev):
+    """pointers handed to the chamfer kernels are checked -- CPU weights / features raise instead of
+    faulting, strided weights give the contiguous result."""
+    from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance
+
+    x = G(cases.cloud(2401, (4, 200, 3)), dev)
+    y = G(cases.cloud(2402, (4, 260, 3)), dev)
+    xn, yn = G(cases.cloud(2403, (4, 200, 3)), dev), G(cases.cloud(2404, (4, 260, 3)), dev)
+    w = torch.tensor([0.5, 1.0, 2.0, 0.25])
+    with pytest.raises(RuntimeError):
+        chamfer_distance(x, y, weights=w)  # CPU weights
+    with pytest.raises(RuntimeError):
+        chamfer_distance(x, y, x_features={"n": xn.cpu()}, y_features={"n": yn}, feature_names=["n"])
+    wide = torch.stack([w, w * 7], dim=1).to(dev)  # (4, 2): column 0 is a strided view
+    l_s, _ = chamfer_distance(x, y, weights=wide[:, 0])
+    l_c, _ = chamfer_distance(x, y, weights=w.to(dev))
+    assert torch.equal(l_s, l_c)
