@@ -73,6 +73,14 @@ int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* len
 int pointops_knn_grid_fallback_counts(const void* workspace, int64_t N, int64_t P1, int64_t P2,
                                       int64_t K, int32_t* counts, void* stream);
 
+/*
+ * Diagnostics, same contract: stats (N,8) int32 on the device = cells per dimension G[0..2], cell count,
+ * 1 if the cloud was searched through a grid, queries uncertified after the lane pass / after the quad pass /
+ * sent to the whole-cloud scan.  (No reference counterpart; used by tools/ and the distribution benchmarks.)
+ */
+int pointops_knn_grid_stats(const void* workspace, int64_t N, int64_t P1, int64_t P2, int64_t K,
+                            int32_t* stats, void* stream);
+
 /* Replaces `_C.knn_check_version` (reference: csrc/knn/knn.h:161, knn.cu:292-303). */
 int pointops_knn_check_version(int version, int64_t D, int64_t K);
 

@@ -34,6 +34,7 @@ _SIGNATURES = {
                                        _vp, _vp, _vp, _sz, _vp]),
     "pointops_knn_check_version": (_int, [_int, _i64, _i64]),
     "pointops_knn_grid_fallback_counts": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "pointops_knn_grid_stats": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "pointops_knn_points_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                             _i64, _int, _vp, _vp, _vp]),
     "pointops_ball_query_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
@@ -141,6 +142,8 @@ def knn_points_idx(p1, p2, lengths1, lengths2, norm: int, K: int, version: int =
         raise RuntimeError("lengths1/lengths2 must be int64")
     p1, p2 = p1.contiguous(), p2.contiguous()  # reference CUDA path: knn.cu:373-376
     lengths1, lengths2 = lengths1.contiguous(), lengths2.contiguous()
+    # (a self-query -- the same storage for both point sets and both lengths -- is recognised by the C ABI
+    # from pointer equality and sorts the cloud once)
     N, P1, D = p1.shape
     P2 = p2.shape[1]
     if p2.shape[0] != N or p2.shape[2] != D or lengths1.shape != (N,) or lengths2.shape != (N,):
@@ -184,6 +187,31 @@ def knn_grid_fallback_counts(p1, p2, lengths1, lengths2, norm: int, K: int):
         _check(_lib.pointops_knn_grid_fallback_counts(ws.data_ptr(), N, P1, P2, int(K), counts.data_ptr(),
                                                       _stream()), "knn_grid_fallback_counts")
     return idxs, dists, counts
+
+
+def knn_grid_stats(p1, p2, lengths1, lengths2, norm: int, K: int):
+    """Diagnostics: run the grid family and return (idx, dists, stats (N, 8) int32): cells per dimension (3),
+    cell count, grid used, queries uncertified after the lane pass / the quad pass / sent to the whole-cloud scan."""
+    dev = _require_gpu(p1, p2, lengths1, lengths2)
+    p1 = p1.contiguous()
+    p2 = p1 if p2 is p1 else p2.contiguous()
+    N, P1, D = p1.shape
+    P2 = p2.shape[1]
+    if not knn_check_version(3, D, K):
+        raise RuntimeError("grid family needs D <= 3 and K <= 32")
+    with torch.cuda.device(dev):
+        idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
+        dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
+        ws_bytes = _lib.pointops_knn_workspace_bytes(N, P1, P2, D, K, 3)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        stats = torch.zeros((N, 8), dtype=torch.int32, device=dev)
+        _check(_lib.pointops_knn_points_idx(p1.data_ptr(), p2.data_ptr(), lengths1.data_ptr(),
+                                            lengths2.data_ptr(), N, P1, P2, D, int(norm), int(K), 3,
+                                            idxs.data_ptr(), dists.data_ptr(), ws.data_ptr(), ws_bytes,
+                                            _stream()), "knn_points_idx")
+        _check(_lib.pointops_knn_grid_stats(ws.data_ptr(), N, P1, P2, int(K), stats.data_ptr(), _stream()),
+               "knn_grid_stats")
+    return idxs, dists, stats
 
 
 def knn_check_version(version: int, D: int, K: int) -> bool:

@@ -104,3 +104,34 @@ extern "C" int pointops_knn_grid_fallback_counts(const void* workspace, int64_t 
     return check_launch("knn_grid_fallback_counts");
   return POINTOPS_OK;
 }
+
+// grid geometry + fallback counters of the last knn_points_idx call that used `workspace`:
+// stats (N, 8) int32 = G[0], G[1], G[2], ncell, use_grid, uncertified after the lane pass, after the quad pass,
+// sent to the whole-cloud scan
+namespace pointops {
+__global__ void grid_stats_kernel(GridWs ws, int N, int32_t* __restrict__ stats) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const GridCloud g = ws.cloud[n];
+  int32_t* s = stats + (int64_t)n * 8;
+  s[0] = g.G[0];
+  s[1] = g.G[1];
+  s[2] = g.G[2];
+  s[3] = g.ncell;
+  s[4] = g.use_grid;
+  s[5] = ws.fb_count[n];
+  s[6] = ws.fb3_count[n];
+  s[7] = ws.fb2_count[n];
+}
+}  // namespace pointops
+
+extern "C" int pointops_knn_grid_stats(const void* workspace, int64_t N, int64_t P1, int64_t P2, int64_t K,
+                                       int32_t* stats, void* stream) {
+  using namespace pointops;
+  POINTOPS_REQUIRE(workspace != nullptr && stats != nullptr && N > 0, "knn_grid_stats: bad arguments");
+  GridWs ws;
+  grid_carve(&ws, (char*)workspace, N, P1, P2, knn_cell_target((int)K));
+  hipLaunchKernelGGL(grid_stats_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, ws, (int)N,
+                     stats);
+  return check_launch("knn_grid_stats");
+}

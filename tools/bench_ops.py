@@ -66,6 +66,18 @@ def main():
         ms, mn = timeit(lambda: _C.sample_farthest_points(pts, L, Kt, S), warmup=1, iters=3)
         emit("sample_farthest_points B=16 N=131072 K=1024", ms, mn,
              point_updates_per_s=Bc * 1023 * Pc / ms * 1e3, streamed_GBs=Bc * 1023 * Pc * 20 / ms / 1e6)
+        # cluster placement modes (debug.h): 0 round-robin members, 1 XCD-local members, 2 XCD-local + L2 exchange
+        for mode in ("0", "1", "2"):
+            os.environ["POINTOPS_DEBUG"] = "fps_mode=" + mode
+            ms2, mn2 = timeit(lambda: _C.sample_farthest_points(pts, L, Kt, S), warmup=1, iters=5)
+            emit(f"sample_farthest_points B=16 N=131072 K=1024 [fps_mode={mode}]", ms2, mn2, us_per_iteration=ms2 / 1.023)
+        del os.environ["POINTOPS_DEBUG"]
+        for (b, n, k) in ((1, 131072, 1024), (4, 32768, 512), (64, 8192, 256)):
+            Kb = torch.full((b,), k, dtype=torch.int64, device=dev)
+            Lb = torch.full((b,), n, dtype=torch.int64, device=dev)
+            pb = pts[:b, :n].contiguous() if b <= Bc else pts[:, :n].repeat(b // Bc, 1, 1).contiguous()
+            ms2, mn2 = timeit(lambda: _C.sample_farthest_points(pb, Lb, Kb, torch.zeros_like(Kb)), warmup=1, iters=3)
+            emit(f"sample_farthest_points B={b} N={n} K={k}", ms2, mn2)
     if "chamfer" in ops:
         Bq = 8
         l1 = synth.randint(41, 20000, 200000, (Bq,))

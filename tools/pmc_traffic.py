@@ -11,7 +11,10 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
 def per_kernel(d, counter):
@@ -34,7 +37,9 @@ def main():
             kernels[k] = {"fetch_bytes_per_step": 2.0 * fe.get(k, 0.0) * 1024 / steps,
                           "write_bytes_per_step": wr.get(k, 0.0) * 1024 / steps}
     total = sum(v["fetch_bytes_per_step"] + v["write_bytes_per_step"] for v in kernels.values())
-    json.dump({"traffic_bytes_per_step": total, "steps_profiled": steps,
+    import bench  # kernel_source_digest: ties the numbers to the code they were measured on
+
+    json.dump({"traffic_bytes_per_step": total, "steps_profiled": steps, "kernel_source_digest": bench.kernel_source_digest(),
                "correction": "FETCH_SIZE KiB x2 (gfx950 wide-read undercount) + WRITE_SIZE KiB, separate --pmc passes",
                "kernels": kernels}, open(out, "w"), indent=1)
     print(json.dumps({"traffic_bytes_per_step": total}))
