@@ -9,5 +9,6 @@ or a CPU tensor raises.
 """
 __version__ = "0.1.0"
 
-from . import _C  # noqa: E402,F401  loads libpointops_amd.so (raises when it is missing)
-from . import ops  # noqa: E402,F401  registers torch.ops.pointops_amd.*
+# `pytorch3d_pointops_amd.build` must stay importable before the library exists, so nothing is imported here:
+# `functions` (and `structures`, which uses it) load `_C` -- the ctypes boundary, raising when the .so is
+# missing -- and `ops`, which registers torch.ops.pointops_amd.*.
