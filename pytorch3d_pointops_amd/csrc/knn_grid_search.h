@@ -78,7 +78,11 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
   constexpr int kGroupBytes = G * 16;
   static_assert(G % kSub == 0 && G <= kSortedPad, "group geometry");
   __shared__ double s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
-  __shared__ int2 s_rows[kLaneRows + 1][kGridWave];  // per-lane (first record, end) of its non-empty runs, then (0, 0)
+  // per-lane list of its non-empty runs, one word each: first record << 11 | length (<= 2047; a lane with a longer
+  // run -- an over-full cell -- leaves its query to the fallback passes), then zeros.  Packed so that a wave needs
+  // 2.5 KB instead of 5 KB of LDS: with the 8 KB queue that is 15 instead of 12 waves per CU.
+  __shared__ unsigned s_rows[kLaneRows + 1][kGridWave];
+  constexpr int kRunBits = 11, kRunMax = (1 << kRunBits) - 1;
 
   const int lane = threadIdx.x;
   const int total = chunk_prefix[N];
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     for (int t = 0; t < kQueueCap; ++t) s_queue[t * kGridWave + lane] = TopKF64<KC>::empty();
   }
   double* const qbase = s_queue + lane;
-  int2* const rows = &s_rows[0][0];
+  unsigned* const rows = &s_rows[0][0];
   // XCD-aware item order: workgroup b runs on XCD b % 8 (round-robin dispatch), and the chunks are
   // sorted by (cloud, cell).  Each XCD walks its own contiguous eighth of the chunk list, so the
   // ~1000 chunks it has in flight belong to one or two clouds whose sorted records (1 MB at 65536
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     const unsigned thr0 = seed_threshold(lb, whole);
 
     // the lane's non-empty runs, own row first (near-first order tightens the thresholds early)
+    bool overlong = false;
     {
       int cnt = 0;  // rows written so far, as an element offset into s_rows
 #pragma unroll
@@ -141,34 +146,36 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
           const int rowbase = (z * g.G[1] + y) * g.G[0];
           const int s = cstart[rowbase + X0], e = cstart[rowbase + X1 + 1];
           if (e > s) {
-            rows[lane + cnt] = make_int2(s, e);
+            overlong = overlong || e - s > kRunMax;
+            rows[lane + cnt] = ((unsigned)s << kRunBits) | (unsigned)min(e - s, kRunMax);
             cnt += kGridWave;
           }
         }
       }
-      // terminators: every slot from the lane's count on (a finished lane keeps reading (0, 0))
+      if (overlong) cnt = 0;  // this lane does not walk: its query goes to the fallback passes
+      // terminators: every slot from the lane's count on (a finished lane keeps reading 0)
 #pragma unroll
       for (int r = 0; r <= kLaneRows; ++r) {
-        if (r * kGridWave >= cnt) s_rows[r][lane] = make_int2(0, 0);
+        if (r * kGridWave >= cnt) s_rows[r][lane] = 0u;
       }
     }
     int rowi = lane + 2 * kGridWave;  // entry of `rows` after the prefetched one
     const int rowlast = lane + kLaneRows * kGridWave;
     unsigned off;  // byte offset of the lane's next group inside the cloud's record array
     int rem;       // bytes of the current run from `off` on (<= 0: the run is used up)
-    int2 nse;      // the lane's next run, read from LDS one switch ahead (its latency stays off the walk)
+    unsigned nse;  // the lane's next run, read from LDS one switch ahead (its latency stays off the walk)
     {
-      const int2 se = rows[lane];
-      off = (unsigned)se.x * 16u;
-      rem = (se.y - se.x) * 16;
+      const unsigned se = rows[lane];
+      off = (se >> kRunBits) * 16u;
+      rem = (int)(se & (unsigned)kRunMax) * 16;
       nse = rows[lane + kGridWave];
     }
     auto advance = [&]() __attribute__((always_inline)) {
       rem -= kGroupBytes;
       off += kGroupBytes;
       if (rem <= 0) {  // next run of this lane (exec-masked; some lane switches in most iterations)
-        off = (unsigned)nse.x * 16u;
-        rem = (nse.y - nse.x) * 16;
+        off = (nse >> kRunBits) * 16u;
+        rem = (int)(nse & (unsigned)kRunMax) * 16;
         nse = rows[rowi];
         rowi = min(rowi + kGridWave, rowlast);
       }
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
 
     const unsigned kth_bits = top.kth_bits(K);  // the K-th best, not the list's last slot
     const bool full = kth_bits < 0x7f800000u;
-    const bool ok = whole || (full && __uint_as_float(kth_bits) < lb);
+    const bool ok = !overlong && (whole || (full && __uint_as_float(kth_bits) < lb));
     if (active) {
       if (ok) {
         const int64_t row = (int64_t)n * P1 + qi;
