@@ -180,15 +180,41 @@ __global__ __launch_bounds__(kFpsBlock) void fps_kernel(
 // ---------------------------------------------------------------------------
 constexpr int kXcds = 8;
 
+// Argmax keys: (running min-distance bits << 32) | ~index.  Distances are >= +0 (padded slots carry -1.0f), so
+// such a key, read as a double, is a non-NaN double whose order is the order we want: larger distance first,
+// then the LOWER index (std::max_element's first maximum); a padded slot is a negative double, below every real
+// one.  One v_max_f64 therefore replaces "compare distances, compare indices, two selects" -- and v_cndmask_b32
+// pairs on a shared VCC cost ~22 cycles each on gfx950 (tools/valu_microbench.hip).
+__device__ __forceinline__ double fps_max(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float fps_min(float a, float b) {  // IEEE minNum: a NaN distance never replaces the minimum
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double fps_wave_max(double k) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const int hi = __shfl_xor(__double2hiint(k), off, kWave);
+    const int lo = __shfl_xor(__double2loint(k), off, kWave);
+    k = fps_max(k, __hiloint2double(hi, lo));
+  }
+  return k;
+}
+
 __device__ __forceinline__ unsigned xcc_id() {
   return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;  // HW_REG_XCC_ID[3:0]
 }
 
 // wave 0 of a member: wait until all G slots of `row` are non-zero, return their maximum (every lane);
-// 0 after `spin_limit` polls without success
+// 0 after `spin_limit` polls without success.  Slot values are argmax keys (or the tiny placeholders 1 /
+// 0x100 | xcc of the placement round): non-negative doubles, so the maximum is again v_max_f64.
 __device__ __forceinline__ unsigned long long fps_gather_row(const unsigned long long* __restrict__ row, int G,
                                                              int lane, unsigned spin_limit) {
-  unsigned long long best = 0ull;
+  double best = 0.0;
   bool ok = true;
   for (int base = 0; base < G && ok; base += kWave) {
     const int m = base + lane;
@@ -203,16 +229,10 @@ __device__ __forceinline__ unsigned long long fps_gather_row(const unsigned long
         break;
       }
     }
-    best = mine > best ? mine : best;
+    best = fps_max(best, __longlong_as_double((long long)mine));
   }
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) {
-    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), off, kWave);
-    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best, off, kWave);
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-    best = o > best ? o : best;
-  }
-  return ok ? best : 0ull;
+  best = fps_wave_max(best);
+  return ok ? (unsigned long long)__double_as_longlong(best) : 0ull;
 }
 
 template <int DT, int PPT>
@@ -235,8 +255,7 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
     member = j % G;
   }
   if (cluster >= n_clusters) return;  // (grid rounded up to a multiple of 8 * G)
-  __shared__ float s_val[kFpsWaves];
-  __shared__ int s_idx[kFpsWaves];
+  __shared__ double s_key[kFpsWaves];
   __shared__ int s_last;
   __shared__ int s_flag;
 
@@ -254,9 +273,10 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
     if (len <= 0 || kn <= 0) continue;
 
     const float* __restrict__ pts = points + (int64_t)n * P * DT;
-    // this lane's points: p = member*PPT*1024 + i*1024 + tid  (ascending in i)
+    // this lane's points: p = member*PPT*1024 + i*1024 + tid  (ascending in i); mk[i] = argmax key of point i:
+    // hi word = its running min-distance (the only part an iteration rewrites), lo word = ~index
     float px[PPT][DT];
-    float md[PPT];
+    double mk[PPT];
     const int base = member * (PPT * kFpsBlock) + tid;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
       const bool valid = p < len;
 #pragma unroll
       for (int d = 0; d < DT; ++d) px[i][d] = valid ? pts[(int64_t)p * DT + d] : 0.0f;
-      md[i] = valid ? FLT_MAX : -1.0f;  // -1: never the maximum
+      mk[i] = __hiloint2double(__float_as_int(valid ? FLT_MAX : -1.0f), (int)(0xffffffffu - (unsigned)p));  // -1: never the maximum
     }
     int last = (int)start_idxs[n];
     if (last < 0 || last >= len) last = 0;
@@ -297,8 +317,7 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
       float c[DT];
 #pragma unroll
       for (int d = 0; d < DT; ++d) c[d] = pts[(int64_t)last * DT + d];  // wave-uniform, read-only input
-      float best = -1.0f;
-      int besti = 0x7fffffff;
+      double best = __hiloint2double(__float_as_int(-1.0f), 0);
 #pragma unroll
       for (int i = 0; i < PPT; ++i) {
         float acc;
@@ -311,45 +330,32 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
           const float diff = c[d] - px[i][d];
           acc = acc + diff * diff;
         }
-        float m = md[i];
-        if (acc < m) m = acc;  // padded lanes keep -1 (acc >= 0 is never < -1)
-        md[i] = m;
-        if (m > best) {
-          best = m;
-          besti = base + i * kFpsBlock;
-        }
+        // padded slots keep -1 (acc >= 0 is never below it)
+        const float m = fps_min(acc, __int_as_float(__double2hiint(mk[i])));
+        mk[i] = __hiloint2double(__float_as_int(m), __double2loint(mk[i]));
+        best = fps_max(best, mk[i]);
       }
-#pragma unroll
-      for (int off = kWave / 2; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(best, off, kWave);
-        const int oi = __shfl_xor(besti, off, kWave);
-        argmax_combine(best, besti, ov, oi);
-      }
-      if (lane == 0) {
-        s_val[wave] = best;
-        s_idx[wave] = besti;
-      }
+      best = fps_wave_max(best);
+      if (lane == 0) s_key[wave] = best;
       __syncthreads();
       if (wave == 0) {
-        float v = lane < kFpsWaves ? s_val[lane] : -2.0f;
-        int ix = lane < kFpsWaves ? s_idx[lane] : 0x7fffffff;
+        double v = lane < kFpsWaves ? s_key[lane] : __hiloint2double(__float_as_int(-2.0f), 0);
 #pragma unroll
         for (int off = kFpsWaves / 2; off > 0; off >>= 1) {
-          const float ov = __shfl_xor(v, off, kWave);
-          const int oi = __shfl_xor(ix, off, kWave);
-          argmax_combine(v, ix, ov, oi);
+          const int hi = __shfl_xor(__double2hiint(v), off, kWave);
+          const int lo = __shfl_xor(__double2loint(v), off, kWave);
+          v = fps_max(v, __hiloint2double(hi, lo));
         }
-        int win = ix;  // valid in lane 0
+        // this member's key: distance bits << 32 | ~index (never 0); 1 when it holds no valid point
+        const unsigned long long key = __double2hiint(v) >= 0 ? (unsigned long long)__double_as_longlong(v) : 1ull;
+        int win = (int)(0xffffffffu - (unsigned)(key & 0xffffffffull));  // valid in lane 0 (G == 1: the result)
         if (G > 1) {
           // Exchange, whole wave 0: lane 0 publishes this member's key with ONE store into its own slot
-          // of the (cloud, iteration) row -- the 8-byte key IS the message (distance bits << 32 | ~index,
-          // never 0) -- then the lanes poll the G slots of the row (one 128-byte line for G = 16)
-          // until all are non-zero and take the maximum: largest distance, lowest index on ties.
+          // of the (cloud, iteration) row -- the 8-byte key IS the message -- then the lanes poll the G slots of
+          // the row (one 128-byte line for G = 16) until all are non-zero and take the maximum: largest
+          // distance, lowest index on ties.
           unsigned long long* __restrict__ rowk = cslots + (int64_t)k * G;
           if (lane == 0) {
-            const unsigned long long key =
-                (v >= 0.0f) ? (((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xffffffffu - (unsigned)ix))
-                            : 1ull;  // this member holds no valid point (below every real key)
             if (same_xcd) __hip_atomic_store(rowk + member, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_store(rowk + member, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }

@@ -35,7 +35,7 @@
 namespace pointops {
 
 // list capacity of the search kernels (sorting networks exist for powers of two)
-static int grid_kc(int K) { return K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : 32; }
+static int grid_kc(int K) { return K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : 64; }
 
 static float knn_cell_target(int K) {
   // the search keeps the KC >= K best but certifies the K-th, so the cells are sized for K points:
@@ -72,7 +72,7 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
   int rc = grid_build(a, ws, b);
   if (rc != POINTOPS_OK) return rc;
   const int kc = grid_kc(a.K);
-  const bool quad = grid_quad_mode(a.P1);
+  const bool quad = kc <= 32 && grid_quad_mode(a.P1);  // (64-slot lists: four of them do not fit a quad's registers)
   switch (a.D) {
     case 1: grid_search_d1(a, ws, norm, kc, quad); break;
     case 2: grid_search_d2(a, ws, norm, kc, quad); break;
@@ -84,7 +84,8 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
   KnnArgs fa = a;
   fa.qlist = ws.fb2_list;
   fa.qcount = ws.fb2_count;
-  launch_knn_bruteforce(fa, norm);
+  if (a.K <= 32) launch_knn_bruteforce(fa, norm);
+  else if ((rc = launch_knn_wide(fa, norm, nullptr)) != POINTOPS_OK) return rc;  // 64-key lists (knn_wide.hip)
   return check_launch("knn_points_idx(grid fallback)");
 }
 

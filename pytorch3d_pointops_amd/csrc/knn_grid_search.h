@@ -650,7 +650,7 @@ static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
                      (const GridCloud*)ws.cloud, (const int*)ws.chunk_prefix, (const float*)ws.edges,
                      (const int*)ws.cell_start, (const float4*)ws.sorted, (const int*)ws.qlist, ws.fb_count,
                      ws.fb_list, ws.fb_kth, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
-  if (quad) {
+  if constexpr (KC <= 32) if (quad) {
     int64_t wx = a.P1 / (32 * kQuadQueries);  // a few % of a cloud arrive here
     wx = wx < 8 ? 8 : wx > 4096 ? 4096 : wx;
     hipLaunchKernelGGL((knn_grid_quad_kernel<D, KC, NORM>), dim3((unsigned)wx, (unsigned)a.N), dim3(kGridWave), 0,
@@ -674,7 +674,8 @@ void grid_search_dispatch(const KnnArgs& a, const GridWs& ws, int kc, bool quad)
     case 4: launch_grid_passes<D, 4, NORM>(a, ws, quad); break;
     case 8: launch_grid_passes<D, 8, NORM>(a, ws, quad); break;
     case 16: launch_grid_passes<D, 16, NORM>(a, ws, quad); break;
-    default: launch_grid_passes<D, 32, NORM>(a, ws, quad); break;
+    case 32: launch_grid_passes<D, 32, NORM>(a, ws, quad); break;
+    default: launch_grid_passes<D, 64, NORM>(a, ws, false); break;
   }
 }
 

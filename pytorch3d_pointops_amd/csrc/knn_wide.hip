@@ -98,7 +98,8 @@ template <int KC, int NORM, int WG>
 __global__ __launch_bounds__(WG) void knn_wide_kernel(
     const float* __restrict__ p1, const float* __restrict__ p2, const int64_t* __restrict__ lengths1,
     const int64_t* __restrict__ lengths2, int P1, int P2, int D, int K, int tiles_per_cloud, int S,
-    unsigned long long* __restrict__ partial, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+    unsigned long long* __restrict__ partial, const int* __restrict__ qlist, const int* __restrict__ qcount,
+    int64_t* __restrict__ idxs, float* __restrict__ dists) {
   extern __shared__ float s_dyn[];
   float* __restrict__ s_q = s_dyn;  // [D][WG]
   const int n = blockIdx.x / tiles_per_cloud;  // wave-uniform
@@ -112,12 +113,17 @@ __global__ __launch_bounds__(WG) void knn_wide_kernel(
   if (len2 > P2) len2 = P2;
   if (len2 < 0) len2 = 0;
 
+  // With `qlist` the workgroup's queries are qlist[n*P1 + i0 ..] (the exact fallback pass of the grid search
+  // for lists longer than the register scan takes): gathered rows instead of a contiguous tile.
+  const int* __restrict__ ql = qlist != nullptr ? qlist + (int64_t)n * P1 : nullptr;
+  const int nlist = ql != nullptr ? qcount[n] : P1;
+  if (i0 >= nlist) return;  // (wave-uniform)
   // query tile, transposed (coalesced global reads of the tile's contiguous rows)
-  const int nq = min(WG, P1 - i0);
+  const int nq = min(WG, nlist - i0);
   const float* __restrict__ src = p1 + ((int64_t)n * P1 + i0) * D;
   for (int f = lane; f < nq * D; f += WG) {
     const int r = f / D, d = f - r * D;
-    s_q[d * WG + r] = src[f];
+    s_q[d * WG + r] = ql != nullptr ? p1[((int64_t)n * P1 + ql[i0 + r]) * D + d] : src[f];
   }
   for (int f = nq * D + lane; f < WG * D; f += WG) {  // lanes beyond the cloud: harmless zeros
     const int r = f / D, d = f - r * D;
@@ -126,28 +132,29 @@ __global__ __launch_bounds__(WG) void knn_wide_kernel(
   __syncthreads();
 
   const float* __restrict__ q = p2 + (int64_t)n * P2 * D;
-  const bool live = i < len1;
-  const int64_t row = (int64_t)n * P1 + i;
+  const int qi = ql != nullptr ? (i < nlist ? ql[i] : 0) : i;  // output row of this lane
+  const bool live = ql != nullptr ? i < nlist : i < len1;
+  const bool owns_row = ql != nullptr ? i < nlist : i < P1;
+  const int64_t row = (int64_t)n * P1 + qi;
 
   if constexpr (KC == kLongKC) {
-    unsigned long long* __restrict__ s_queue = reinterpret_cast<unsigned long long*>(s_dyn + (size_t)D * WG);
-    TopKLex<KC> top;
+    // 64-bit (dist, idx) keys ordered through the FP64 pipe (sort_net.h); free queue slots hold the empty key
+    double* __restrict__ s_queue = reinterpret_cast<double*>(s_dyn + (size_t)D * WG);
+#pragma unroll
+    for (int t = 0; t < kLongQueue; ++t) s_queue[t * WG + lane] = TopKF64<KC>::empty();
+    TopKF64<KC> top;
     top.init();
     unsigned thr = 0x7f800000u;  // distance bits a candidate must not exceed (stale between flushes)
     int qn = 0;
     auto flush = [&]() {
-      unsigned long long qk[kLongQueue];
+      double qk[kLongQueue];
 #pragma unroll
-      for (int t = 0; t < kLongQueue; ++t) {
-        const unsigned long long v = s_queue[t * WG + lane];
-        qk[t] = t < qn ? v : TopKLex<KC>::kEmpty;
-      }
+      for (int t = 0; t < kLongQueue; ++t) qk[t] = s_queue[t * WG + lane];
+#pragma unroll
+      for (int t = 0; t < kLongQueue; ++t) s_queue[t * WG + lane] = TopKF64<KC>::empty();
       bitonic_sort<kLongQueue>(qk);
 #pragma unroll
-      for (int t = 0; t < kLongQueue; ++t) {  // list slot KC-1-t meets queue entry t
-        const unsigned long long a = top.key[KC - 1 - t];
-        top.key[KC - 1 - t] = qk[t] < a ? qk[t] : a;
-      }
+      for (int t = 0; t < kLongQueue; ++t) top.key[KC - 1 - t] = kmin(top.key[KC - 1 - t], qk[t]);  // list slot KC-1-t meets queue entry t
       bitonic_merge<KC>(top.key);
       qn = 0;
       thr = top.worst_bits();
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(WG) void knn_wide_kernel(
       // an equal distance with a larger index (every later candidate) still passes `<=`; the
       // 64-bit key order then drops it at the merge, so the list stays in (dist, idx) order
       if (__float_as_uint(d) <= thr) {
-        s_queue[qn * WG + lane] = TopKLex<KC>::make(d, j);
+        s_queue[qn * WG + lane] = TopKF64<KC>::make(d, j);
         ++qn;
       }
     };
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(WG) void knn_wide_kernel(
       if (__any(qn > kLongQueue - kWideJ)) flush();
     }
     flush();
-    if (i < P1) {
+    if (owns_row) {
       const int kvalid = live ? min(K, len2) : 0;
       int64_t* __restrict__ oi = idxs + row * K;
       float* __restrict__ od = dists + row * K;
@@ -206,8 +213,8 @@ __global__ __launch_bounds__(WG) void knn_wide_kernel(
       if (acc[0] < top.worst()) top.insert(acc[0], j);
     }
     if (S == 1) {
-      if (i < P1) write_row<KC>(top, K, live ? len2 : 0, idxs + row * K, dists + row * K);
-    } else if (i < P1) {
+      if (owns_row) write_row<KC>(top, K, live ? len2 : 0, idxs + row * K, dists + row * K);
+    } else if (owns_row) {
       // partial list of this slice as (dist bits, idx) keys; empty slots order last
       unsigned long long* __restrict__ o = partial + (row * S + split) * K;
       const int have = min(K, jend - jbeg);
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(WG) void knn_wide_kernel(
       wide_dists<1, NORM, WG>(s_q, lane, q, j, D, acc);
       top.offer(acc[0], j);
     }
-    if (i < P1) {
+    if (owns_row) {
       const int kvalid = live ? top.cnt : 0;  // = min(K, len2)
       int64_t* __restrict__ oi = idxs + row * K;
       float* __restrict__ od = dists + row * K;
@@ -258,7 +265,7 @@ static int launch_wide(const KnnArgs& a, size_t lds, int S, void* workspace) {
   const int tiles = (int)ceil_div(a.P1, WG);
   if (a.N * tiles >= (1LL << 31)) return POINTOPS_EINVAL;
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * tiles), (unsigned)S), dim3(WG), lds, a.stream, a.p1, a.p2, a.l1, a.l2,
-                     a.P1, a.P2, a.D, a.K, tiles, S, (unsigned long long*)workspace, a.idxs, a.dists);
+                     a.P1, a.P2, a.D, a.K, tiles, S, (unsigned long long*)workspace, a.qlist, a.qcount, a.idxs, a.dists);
   if (KC > 0 && KC <= 32 && S > 1) knn_merge_partials(a, S, workspace);
   return POINTOPS_OK;
 }

@@ -1089,3 +1089,24 @@ def test_chamfer_device_and_layout_checks(dev):
     l_s, _ = chamfer_distance(x, y, weights=wide[:, 0])
     l_c, _ = chamfer_distance(x, y, weights=w.to(dev))
     assert torch.equal(l_s, l_c)
+
+
+@pytest.mark.parametrize("K,norm", [(33, 2), (40, 2), (64, 2), (64, 1)])
+def test_knn_grid_long_lists(dev, oracle, K, norm):
+    """K in (32, 64] through the grid family (64-slot lists in the lane search, no quad pass, the long-list
+    brute-force kernel as the exact fallback for what stays uncertified): ragged clouds, a cluster, a cloud
+    shorter than K and one without a usable grid, against the oracle and against the brute-force family."""
+    from pytorch3d_pointops_amd.functions import knn_points
+
+    p1 = cases.cloud(2501, (4, 2500, 3))
+    p2 = cases.cloud(2502, (4, 12000, 3))
+    p2[1] = (p2[1] ** np.float32(3.0)).astype(np.float32)  # clustered
+    p2[3, :, :] = p2[3, :1, :]  # all identical: one cell, everything ties
+    l1 = np.array([2500, 2500, 900, 300])
+    l2 = np.array([12000, 7000, K - 3, 12000])
+    r = knn_points(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm=norm, K=K, version=3)
+    oi, od = oracle.knn_points_idx(p1, p2, l1, l2, norm, K)
+    assert np.array_equal(r.idx.cpu().numpy(), oi)
+    assert np.array_equal(bits(r.dists.cpu().numpy()), bits(od))
+    r0 = knn_points(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm=norm, K=K, version=0)
+    assert torch.equal(r0.idx, r.idx) and torch.equal(r0.dists, r.dists)
