@@ -195,6 +195,106 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Query ORDER for the clouds the index-order scan keeps (dense balls).  A wave of the scan kernel runs until
+// ALL of its 64 queries have their K hits, and how long a query scans is set by how much of its ball lies
+// inside the cloud: ~1/8 of the ball for a query in a corner of a uniform cube, so its scan is ~8x as long as
+// an interior one, and with queries in storage order nearly every wave holds such a query.  Sorting the
+// query ids by a coarse 8x8x8 cell of the cloud's bounding box puts queries with similar clipping -- and
+// similar hit patterns -- in the same wave.  The scan kernel then takes these clouds in its list mode
+// (qlist = all queries, coarse-cell order); results do not depend on the order.
+// ---------------------------------------------------------------------------
+constexpr int kOrderG = 8, kOrderBins = kOrderG * kOrderG * kOrderG;
+constexpr int kOrderBlock = 256, kOrderPerThread = 8;
+
+template <int D>
+__device__ __forceinline__ int order_bin(const float* __restrict__ q, const unsigned* __restrict__ bbox) {
+  int bin = 0;
+#pragma unroll
+  for (int d = D - 1; d >= 0; --d) {
+    const float lo = funkey(bbox[d]), hi = funkey(bbox[3 + d]);
+    const float t = (q[d] - lo) * ((float)kOrderG / fmaxf(hi - lo, FLT_MIN));
+    int c = t < (float)kOrderG ? (int)t : kOrderG - 1;
+    if (!(t >= 0.0f)) c = 0;
+    bin = bin * kOrderG + c;
+  }
+  return bin;
+}
+
+// SCATTER = false: histogram into qcell_count; true: exclusive scan of the 512 counters (every block, in LDS)
+// + scatter through the cursors in qcell_start
+template <int D, bool SCATTER>
+__global__ __launch_bounds__(kOrderBlock) void ball_order_kernel(const float* __restrict__ p1, int P1, GridWs ws) {
+  const int n = blockIdx.y;
+  const GridCloud g = ws.cloud[n];
+  if (g.use_grid || g.len2 <= 0) return;  // grid clouds have their own lists; empty clouds: the scan pads
+  __shared__ int s_bin[kOrderBins];
+  const int tid = threadIdx.x;
+  const int i0 = blockIdx.x * (kOrderBlock * kOrderPerThread);
+  if (i0 >= g.len1) return;
+  int* __restrict__ count = ws.qcell_count + (int64_t)n * ws.cell_cap;
+  int* __restrict__ cursor = ws.qcell_start + (int64_t)n * (ws.cell_cap + 1);
+  for (int b = tid; b < kOrderBins; b += kOrderBlock) s_bin[b] = SCATTER ? count[b] : 0;
+  __syncthreads();
+  if (SCATTER) {  // exclusive scan of 512 counters: two per lane + wave scan + 4 wave totals
+    __shared__ int s_tot[kOrderBlock / kWave];
+    const int a = s_bin[2 * tid], b = s_bin[2 * tid + 1];
+    int inc = a + b;
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int v = __shfl_up(inc, off, kWave);
+      if (lane >= off) inc += v;
+    }
+    if (lane == kWave - 1) s_tot[wave] = inc;
+    __syncthreads();
+    int basev = 0;
+    for (int w = 0; w < wave; ++w) basev += s_tot[w];
+    const int excl = basev + inc - (a + b);
+    __syncthreads();
+    s_bin[2 * tid] = excl;
+    s_bin[2 * tid + 1] = excl + a;
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) ws.fb2_count[n] = g.len1;  // the list holds every query of the cloud
+  }
+  const unsigned* __restrict__ bbox = ws.bbox + n * 8;
+#pragma unroll
+  for (int r = 0; r < kOrderPerThread; ++r) {
+    const int i = i0 + r * kOrderBlock + tid;
+    if (i < g.len1) {
+      const int bin = order_bin<D>(p1 + ((int64_t)n * P1 + i) * D, bbox);
+      if (!SCATTER) {
+        atomicAdd(&s_bin[bin], 1);
+      } else {
+        const int pos = s_bin[bin] + atomicAdd(cursor + bin, 1);
+        ws.fb2_list[(int64_t)n * P1 + pos] = i;
+      }
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (int b = tid; b < kOrderBins; b += kOrderBlock)
+      if (s_bin[b] > 0) atomicAdd(count + b, s_bin[b]);
+  }
+}
+
+// PHASE 0: zero the 512 counters and cursors of the scan-mode clouds (their slices of the query histogram
+// arrays are otherwise unused); PHASE 1, behind the scatter: mark those clouds as "listed"
+template <int PHASE>
+__global__ void ball_order_aux_kernel(GridWs ws, int N) {
+  const int n = blockIdx.x;
+  const GridCloud g = ws.cloud[n];
+  if (g.use_grid || g.len2 <= 0) return;
+  if (PHASE == 0) {
+    for (int b = threadIdx.x; b < kOrderBins; b += blockDim.x) {
+      ws.qcell_count[(int64_t)n * ws.cell_cap + b] = 0;
+      ws.qcell_start[(int64_t)n * (ws.cell_cap + 1) + b] = 0;
+    }
+  } else if (threadIdx.x == 0) {
+    ws.grid_flag[n] = 1;
+  }
+}
+
 constexpr float kBallCellTarget = 2.0f;  // density floor of the cell size; the radius usually decides
 
 size_t ball_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2) {
@@ -240,6 +340,22 @@ int ball_grid_run(const KnnArgs& a, float radius, void* workspace, const int** f
     case 1: ball_run_d<1>(a, radius2, ws, wgs); break;
     case 2: ball_run_d<2>(a, radius2, ws, wgs); break;
     default: ball_run_d<3>(a, radius2, ws, wgs); break;
+  }
+  // scan-mode clouds: all queries, ordered by coarse cell (the histogram arrays of those clouds are unused:
+  // qcell_count was zeroed with the others, qcell_start serves as the scatter cursors)
+  if (debug_knob("ball_order", 1) != 0 && ws.cell_cap >= kOrderBins) {
+    const dim3 og((unsigned)ceil_div(a.P1, kOrderBlock * kOrderPerThread), (unsigned)a.N);
+    hipLaunchKernelGGL(ball_order_aux_kernel<0>, dim3((unsigned)a.N), dim3(256), 0, a.stream, ws, (int)a.N);
+#define PO_ORDER(DD)                                                                                         \
+  hipLaunchKernelGGL((ball_order_kernel<DD, false>), og, dim3(kOrderBlock), 0, a.stream, a.p1, a.P1, ws);     \
+  hipLaunchKernelGGL((ball_order_kernel<DD, true>), og, dim3(kOrderBlock), 0, a.stream, a.p1, a.P1, ws)
+    switch (a.D) {
+      case 1: PO_ORDER(1); break;
+      case 2: PO_ORDER(2); break;
+      default: PO_ORDER(3); break;
+    }
+#undef PO_ORDER
+    hipLaunchKernelGGL(ball_order_aux_kernel<1>, dim3((unsigned)a.N), dim3(64), 0, a.stream, ws, (int)a.N);
   }
   *flag = ws.grid_flag;
   *qcount = ws.fb2_count;

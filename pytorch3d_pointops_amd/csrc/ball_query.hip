@@ -78,6 +78,12 @@ __global__ __launch_bounds__(kBqBlock) void ball_query_kernel(
     // has a bit active; its distance is recomputed from the same operands (bit-identical).
     const int room = active ? K : 0;
     int j = 0;
+    // hit bit of one candidate into the lane's mask: `mask = 2 mask + (acc < radius2)` is ONE v_addc_co_u32 whose
+    // carry-in is the lane's bit of the compare result (cmp + select + shift + or: four instructions otherwise).
+    // The first candidate of a group therefore ends up in the HIGHEST used bit.
+    auto push_hit = [&](unsigned& mask, float acc) __attribute__((always_inline)) {
+      asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "s"(radius2), "v"(acc) : "vcc");
+    };
     while (j < len2 && __any(count < room)) {
       unsigned mask = 0u;
       const int jg = j;
@@ -87,24 +93,21 @@ __global__ __launch_bounds__(kBqBlock) void ball_query_kernel(
 #pragma unroll
         for (int u = 0; u < kBqTile * DT; ++u) t[u] = q[(int64_t)j * DT + u];  // wave-uniform -> s_load
 #pragma unroll
-        for (int jj = 0; jj < kBqTile; ++jj) {
-          const float acc = dist_to(t + jj * DT);
-          mask |= (acc < radius2 ? 1u : 0u) << (unsigned)(j - jg + jj);
-        }
+        for (int jj = 0; jj < kBqTile; ++jj) push_hit(mask, dist_to(t + jj * DT));
       }
       for (; j < g_end; ++j) {
         float t[DT];
 #pragma unroll
         for (int u = 0; u < DT; ++u) t[u] = q[(int64_t)j * DT + u];
-        const float acc = dist_to(t);
-        mask |= (acc < radius2 ? 1u : 0u) << (unsigned)(j - jg);
+        push_hit(mask, dist_to(t));
       }
+      const int top = g_end - jg - 1;  // bit of the group's first candidate
       if (count >= room) mask = 0u;
       while (__any(mask != 0u)) {
         if (mask != 0u) {
-          const int b = __builtin_ctz(mask);
-          mask &= mask - 1u;
-          const int jh = jg + b;
+          const int b = 31 - __builtin_clz(mask);  // highest set bit = lowest index
+          mask &= ~(1u << b);
+          const int jh = jg + (top - b);
           float pb[DT];
 #pragma unroll
           for (int d = 0; d < DT; ++d) pb[d] = q[(int64_t)jh * DT + d];  // per-lane gather (L2-resident)

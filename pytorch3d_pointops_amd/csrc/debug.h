@@ -8,6 +8,7 @@
 //   grid_c_scale=F     multiply the grid KNN's points-per-cell target (sweeps)
 //   ball_grid=0|1      ball query: never / whenever possible through the grid (default: by shape)
 //   ball_factor=F      ball query: grid-or-scan crossover constant
+//   ball_order=0       ball query: scan-mode clouds keep their queries in storage order (no coarse-cell order)
 //   knn_bwd_mode=a|t   knn backward grad_p2: device atomics / LDS tiles;  knn_bwd_split=S
 //   gather_bwd_mode=a|t, gather_bwd_split=S   the same for knn_gather's backward
 //   fps_mode=0|1|2     FPS clusters: round-robin members / XCD-local members / XCD-local + L2 exchange
