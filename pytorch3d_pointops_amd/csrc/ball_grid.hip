@@ -200,11 +200,11 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
 // ALL of its 64 queries have their K hits, and how long a query scans is set by how much of its ball lies
 // inside the cloud: ~1/8 of the ball for a query in a corner of a uniform cube, so its scan is ~8x as long as
 // an interior one, and with queries in storage order nearly every wave holds such a query.  Sorting the
-// query ids by a coarse 8x8x8 cell of the cloud's bounding box puts queries with similar clipping -- and
+// query ids by a coarse 16x16x16 cell of the cloud's bounding box puts queries with similar clipping -- and
 // similar hit patterns -- in the same wave.  The scan kernel then takes these clouds in its list mode
 // (qlist = all queries, coarse-cell order); results do not depend on the order.
 // ---------------------------------------------------------------------------
-constexpr int kOrderG = 8, kOrderBins = kOrderG * kOrderG * kOrderG;
+constexpr int kOrderG = 16, kOrderBins = kOrderG * kOrderG * kOrderG;
 constexpr int kOrderBlock = 256, kOrderPerThread = 8;
 
 template <int D>
@@ -236,10 +236,17 @@ __global__ __launch_bounds__(kOrderBlock) void ball_order_kernel(const float* __
   int* __restrict__ cursor = ws.qcell_start + (int64_t)n * (ws.cell_cap + 1);
   for (int b = tid; b < kOrderBins; b += kOrderBlock) s_bin[b] = SCATTER ? count[b] : 0;
   __syncthreads();
-  if (SCATTER) {  // exclusive scan of 512 counters: two per lane + wave scan + 4 wave totals
+  if (SCATTER) {  // exclusive scan of the counters: kPer per lane + wave scan + 4 wave totals
     __shared__ int s_tot[kOrderBlock / kWave];
-    const int a = s_bin[2 * tid], b = s_bin[2 * tid + 1];
-    int inc = a + b;
+    constexpr int kPer = kOrderBins / kOrderBlock;
+    int v[kPer];
+    int inc = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      v[u] = s_bin[kPer * tid + u];
+      inc += v[u];
+    }
+    const int mine = inc;
     const int lane = tid & (kWave - 1), wave = tid / kWave;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -248,12 +255,14 @@ __global__ __launch_bounds__(kOrderBlock) void ball_order_kernel(const float* __
     }
     if (lane == kWave - 1) s_tot[wave] = inc;
     __syncthreads();
-    int basev = 0;
-    for (int w = 0; w < wave; ++w) basev += s_tot[w];
-    const int excl = basev + inc - (a + b);
+    int run = inc - mine;
+    for (int w = 0; w < wave; ++w) run += s_tot[w];
     __syncthreads();
-    s_bin[2 * tid] = excl;
-    s_bin[2 * tid + 1] = excl + a;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      s_bin[kPer * tid + u] = run;
+      run += v[u];
+    }
     __syncthreads();
     if (blockIdx.x == 0 && tid == 0) ws.fb2_count[n] = g.len1;  // the list holds every query of the cloud
   }
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(kOrderBlock) void ball_order_kernel(const float* __
   }
 }
 
-// PHASE 0: zero the 512 counters and cursors of the scan-mode clouds (their slices of the query histogram
+// PHASE 0: zero the counters and cursors of the scan-mode clouds (their slices of the query histogram
 // arrays are otherwise unused); PHASE 1, behind the scatter: mark those clouds as "listed"
 template <int PHASE>
 __global__ void ball_order_aux_kernel(GridWs ws, int N) {

@@ -24,7 +24,7 @@
 namespace pointops {
 
 constexpr int kBqBlock = 256;
-constexpr int kBqTile = 8;
+constexpr int kBqTile = 8;  // points per scalar-load group of the storage-order scan
 
 template <int DT>
 __global__ __launch_bounds__(kBqBlock) void ball_query_kernel(
@@ -38,7 +38,8 @@ __global__ __launch_bounds__(kBqBlock) void ball_query_kernel(
   const int tile = blockIdx.x - n * tiles_per_cloud;
   int i = tile * kBqBlock + threadIdx.x;
   bool in_range = i < P1;
-  if (grid_flag != nullptr && grid_flag[n]) {  // wave-uniform: this cloud went through the grid
+  const bool listed = grid_flag != nullptr && grid_flag[n];  // (workgroup-uniform)
+  if (listed) {  // this cloud's queries come from a list: uncertified by the grid, or coarse-cell order
     if (tile * kBqBlock >= qcount[n]) return;
     in_range = i < qcount[n];
     i = in_range ? qlist[(int64_t)n * P1 + i] : 0;
@@ -77,44 +78,157 @@ __global__ __launch_bounds__(kBqBlock) void ball_query_kernel(
     // expansion loop per group then writes the hits in bit (= index) order with every lane that still
     // has a bit active; its distance is recomputed from the same operands (bit-identical).
     const int room = active ? K : 0;
-    int j = 0;
-    // hit bit of one candidate into the lane's mask: `mask = 2 mask + (acc < radius2)` is ONE v_addc_co_u32 whose
-    // carry-in is the lane's bit of the compare result (cmp + select + shift + or: four instructions otherwise).
-    // The first candidate of a group therefore ends up in the HIGHEST used bit.
-    auto push_hit = [&](unsigned& mask, float acc) __attribute__((always_inline)) {
-      asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "s"(radius2), "v"(acc) : "vcc");
-    };
-    while (j < len2 && __any(count < room)) {
-      unsigned mask = 0u;
-      const int jg = j;
-      const int g_end = (j + 32 < len2) ? j + 32 : len2;
-      for (; j + kBqTile <= g_end; j += kBqTile) {
-        float t[kBqTile * DT];
-#pragma unroll
-        for (int u = 0; u < kBqTile * DT; ++u) t[u] = q[(int64_t)j * DT + u];  // wave-uniform -> s_load
-#pragma unroll
-        for (int jj = 0; jj < kBqTile; ++jj) push_hit(mask, dist_to(t + jj * DT));
+    if (listed) {
+      const int lane = threadIdx.x & (kWave - 1);
+      // Bounding box of the wave's active queries (exact min / max).  Its queries come in coarse-cell order
+      // (ball_grid.hip) or through the grid's fallback list, so the box is small next to the cloud.
+      float blo[DT], bhi[DT];
+  #pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        float mn = active ? a[d] : __builtin_inff(), mx = active ? a[d] : -__builtin_inff();
+  #pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+          mn = fminf(mn, __shfl_xor(mn, off, kWave));
+          mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+        }
+        blo[d] = mn;
+        bhi[d] = mx;
       }
-      for (; j < g_end; ++j) {
-        float t[DT];
-#pragma unroll
-        for (int u = 0; u < DT; ++u) t[u] = q[(int64_t)j * DT + u];
-        push_hit(mask, dist_to(t));
-      }
-      const int top = g_end - jg - 1;  // bit of the group's first candidate
-      if (count >= room) mask = 0u;
-      while (__any(mask != 0u)) {
-        if (mask != 0u) {
-          const int b = 31 - __builtin_clz(mask);  // highest set bit = lowest index
-          mask &= ~(1u << b);
-          const int jh = jg + (top - b);
+      // The wave consumes p2 in TILES of 64 points, one per lane:
+      //  1. every lane tests ITS point against the wave's box: LB = the scan's own distance expression on the
+      //     per-dimension gaps fl(lo - c) / fl(c - hi) / 0.  fp32 subtraction, squaring and the sums are monotone,
+      //     so every query's COMPUTED distance to the point is >= LB; LB >= radius2 proves no lane can hit;
+      //  2. the surviving points (a ballot; ~10-15 % of a uniform cube at r = 0.2) are broadcast one by one
+      //     (v_readlane) and tested by all lanes: a hit sets bit b of the lane's 64-bit tile mask;
+      //  3. the lanes write their hits in bit (= index) order; the distance is recomputed from the same operands.
+      // (Round 1 tested every point in every lane through the scalar path: ~35 cycles per wave-point for what is
+      // now one vector instruction per 64 points plus ~50 cycles per surviving point.)
+      int j0 = 0;
+      float cn[DT];  // the NEXT tile's point of this lane, loaded one tile ahead
+  #pragma unroll
+      for (int d = 0; d < DT; ++d) cn[d] = lane < len2 ? q[(int64_t)lane * DT + d] : 0.0f;
+      while (j0 < len2 && __any(count < room)) {
+        const int jc = j0 + lane;
+        float c[DT];
+  #pragma unroll
+        for (int d = 0; d < DT; ++d) c[d] = cn[d];
+        {
+          const int jn = jc + kWave;
+  #pragma unroll
+          for (int d = 0; d < DT; ++d) cn[d] = jn < len2 ? q[(int64_t)jn * DT + d] : 0.0f;
+        }
+        float lb;
+        {
+          float g0 = fmaxf(fmaxf(blo[0] - c[0], c[0] - bhi[0]), 0.0f);
+          lb = g0 * g0;
+  #pragma unroll
+          for (int d = 1; d < DT; ++d) {
+            const float gd = fmaxf(fmaxf(blo[d] - c[d], c[d] - bhi[d]), 0.0f);
+            lb = lb + gd * gd;
+          }
+        }
+        unsigned long long cand = __ballot(jc < len2 && lb < radius2);
+        unsigned mlo = 0u, mhi = 0u;  // the lane's hits among the tile's points
+        if (__popcll(cand) >= 48 && j0 + kWave <= len2) {
+          // Most of the tile survives (queries in storage order, or a box as large as the cloud): the broadcast
+          // loop would cost more than testing all 64 points through the scalar path (wave-uniform addresses ->
+          // s_load, SGPR operands).  `mask = 2 mask + hit` is ONE v_addc_co_u32 whose carry-in is the lane's bit
+          // of the compare; the first point ends up in the highest bit, hence the bit reversal.
+          unsigned r0 = 0u, r1 = 0u;
+          auto push_hit = [&](unsigned& mask, float acc) __attribute__((always_inline)) {
+            asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "s"(radius2), "v"(acc) : "vcc");
+          };
+          for (int jj = 0; jj < 32; jj += 8) {
+            float t[8 * DT];
+  #pragma unroll
+            for (int u = 0; u < 8 * DT; ++u) t[u] = q[(int64_t)(j0 + jj) * DT + u];
+  #pragma unroll
+            for (int u = 0; u < 8; ++u) push_hit(r0, dist_to(t + u * DT));
+          }
+          for (int jj = 32; jj < 64; jj += 8) {
+            float t[8 * DT];
+  #pragma unroll
+            for (int u = 0; u < 8 * DT; ++u) t[u] = q[(int64_t)(j0 + jj) * DT + u];
+  #pragma unroll
+            for (int u = 0; u < 8; ++u) push_hit(r1, dist_to(t + u * DT));
+          }
+          mlo = __brev(r0);
+          mhi = __brev(r1);
+          cand = 0ull;
+        }
+        while (cand != 0ull) {  // wave-uniform
+          const int b = __builtin_ctzll(cand);
+          cand &= cand - 1ull;
           float pb[DT];
-#pragma unroll
-          for (int d = 0; d < DT; ++d) pb[d] = q[(int64_t)jh * DT + d];  // per-lane gather (L2-resident)
-          orow_i[count] = jh;
-          orow_d[count] = dist_to(pb);
-          ++count;
-          if (count >= room) mask = 0u;
+  #pragma unroll
+          for (int d = 0; d < DT; ++d) pb[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c[d]), b));
+          const bool hit = dist_to(pb) < radius2;
+          const unsigned bit = 1u << (b & 31);
+          if (b < 32) mlo |= hit ? bit : 0u;
+          else mhi |= hit ? bit : 0u;
+        }
+        if (count >= room) mlo = mhi = 0u;
+        while (__any((mlo | mhi) != 0u)) {  // wave-uniform loop: every lane takes part in the shuffles
+          const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+          const bool has = m != 0ull;
+          const int b = has ? __builtin_ctzll(m) : 0;
+          float ph[DT];
+  #pragma unroll
+          for (int d = 0; d < DT; ++d) ph[d] = __shfl(c[d], b, kWave);  // the tile still sits in the lanes
+          if (has) {
+            if (b < 32) mlo &= mlo - 1u;
+            else mhi &= mhi - 1u;
+            orow_i[count] = j0 + b;
+            orow_d[count] = dist_to(ph);
+            ++count;
+            if (count >= room) mlo = mhi = 0u;
+          }
+        }
+        j0 += kWave;
+      }
+    } else {
+      // Queries in storage order (small calls without workspace): the wave's box is the cloud, nothing is
+      // rejected, so every point goes through the scalar path (wave-uniform address -> s_load -> SGPR operands),
+      // 32 points per round, hits collected as a per-lane bit mask and written by one expansion loop.
+      int j = 0;
+      // hit bit of one candidate into the lane's mask: `mask = 2 mask + (acc < radius2)` is ONE v_addc_co_u32 whose
+      // carry-in is the lane's bit of the compare result (cmp + select + shift + or: four instructions otherwise).
+      // The first candidate of a group therefore ends up in the HIGHEST used bit.
+      auto push_hit = [&](unsigned& mask, float acc) __attribute__((always_inline)) {
+        asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "s"(radius2), "v"(acc) : "vcc");
+      };
+      while (j < len2 && __any(count < room)) {
+        unsigned mask = 0u;
+        const int jg = j;
+        const int g_end = (j + 32 < len2) ? j + 32 : len2;
+        for (; j + kBqTile <= g_end; j += kBqTile) {
+          float t[kBqTile * DT];
+  #pragma unroll
+          for (int u = 0; u < kBqTile * DT; ++u) t[u] = q[(int64_t)j * DT + u];  // wave-uniform -> s_load
+  #pragma unroll
+          for (int jj = 0; jj < kBqTile; ++jj) push_hit(mask, dist_to(t + jj * DT));
+        }
+        for (; j < g_end; ++j) {
+          float t[DT];
+  #pragma unroll
+          for (int u = 0; u < DT; ++u) t[u] = q[(int64_t)j * DT + u];
+          push_hit(mask, dist_to(t));
+        }
+        const int top = g_end - jg - 1;  // bit of the group's first candidate
+        if (count >= room) mask = 0u;
+        while (__any(mask != 0u)) {
+          if (mask != 0u) {
+            const int b = 31 - __builtin_clz(mask);  // highest set bit = lowest index
+            mask &= ~(1u << b);
+            const int jh = jg + (top - b);
+            float pb[DT];
+  #pragma unroll
+            for (int d = 0; d < DT; ++d) pb[d] = q[(int64_t)jh * DT + d];  // per-lane gather (L2-resident)
+            orow_i[count] = jh;
+            orow_d[count] = dist_to(pb);
+            ++count;
+            if (count >= room) mask = 0u;
+          }
         }
       }
     }
