@@ -284,12 +284,19 @@ constexpr int kBinBlock = 1024;
 constexpr int kBinPerThread = 8;  // tile of 8192 points: 4096 / 8192 / 16384 / 32768 measured 0.988 / 0.969 / 0.987 / 1.125 ms per cfg2 step (chamfer cfg4: 1.14 / 1.13 / 1.22 / 1.66 ms)
 constexpr int kBinTile = kBinBlock * kBinPerThread;
 
-template <int D, bool SCATTER, bool IS_QUERY, bool PAD_ROWS>
-__global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __restrict__ pts, int P, int K, GridWs ws,
+// One launch bins BOTH sets: blockIdx.z = 0 the points of p2, 1 the queries of p1 (QUERIES = false: points only,
+// the self-query case).
+template <int D, bool SCATTER, bool QUERIES>
+__global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __restrict__ p2, int P2,
+                                                           const float* __restrict__ p1, int P1, int K, GridWs ws,
                                                            int64_t* __restrict__ idxs, float* __restrict__ dists) {
   __shared__ int s_hist[kBinLdsBins];
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
+  const bool IS_QUERY = QUERIES && blockIdx.z == 1;   // (workgroup-uniform)
+  const bool PAD_ROWS = QUERIES ? IS_QUERY : true;    // the pass over the query index space also pads rows
+  const float* __restrict__ pts = IS_QUERY ? p1 : p2;
+  const int P = IS_QUERY ? P1 : P2;
   const GridCloud g = ws.cloud[n];  // wave-uniform
   const int len = IS_QUERY ? g.len1 : g.len2;
   const int nbins = g.ncell;
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __rest
   const int i0 = blockIdx.x * kBinTile + tid;
   if (blockIdx.x * kBinTile >= P) return;
 
-  if (PAD_ROWS) {
+  if (PAD_ROWS && !SCATTER) {
     // rows that get no search: zeros for padded queries (knn_cpu.cpp:25-26); whole-cloud list
     // when this cloud has no usable grid
 #pragma unroll 4
@@ -552,25 +559,21 @@ size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, flo
 
 template <int D>
 static void build_d(const KnnArgs& a, const GridWs& ws, bool same) {
-  const dim3 g2((unsigned)ceil_div(a.P2, kBinTile), (unsigned)a.N), g1((unsigned)ceil_div(a.P1, kBinTile), (unsigned)a.N);
   const int chunks = (ws.cell_cap + kScanChunk - 1) / kScanChunk;
-  const unsigned which = same ? 1u : 2u;  // scans: points only / points and queries
-#define PO_BIN(SCT, QRY, PAD, GRID, PTS, PP)                                                                          \
-  hipLaunchKernelGGL((grid_bin_kernel<D, SCT, QRY, PAD>), GRID, dim3(kBinBlock), 0, a.stream, PTS, PP, a.K, ws, a.idxs, \
-                     a.dists)
-  if (same) {
-    PO_BIN(false, false, true, g2, a.p2, a.P2);
-  } else {
-    PO_BIN(false, false, false, g2, a.p2, a.P2);
-    PO_BIN(false, true, true, g1, a.p1, a.P1);
-  }
+  const unsigned which = same ? 1u : 2u;  // points only / points and queries
+  const dim3 gb((unsigned)ceil_div(same ? a.P2 : (a.P2 > a.P1 ? a.P2 : a.P1), kBinTile), (unsigned)a.N, which);
+#define PO_BIN(SCT, QRY)                                                                                          \
+  hipLaunchKernelGGL((grid_bin_kernel<D, SCT, QRY>), gb, dim3(kBinBlock), 0, a.stream, a.p2, a.P2, a.p1, a.P1, a.K, \
+                     ws, a.idxs, a.dists)
+  if (same) PO_BIN(false, false);
+  else PO_BIN(false, true);
   hipLaunchKernelGGL(grid_scan_partial_kernel, dim3((unsigned)chunks, (unsigned)a.N, which), dim3(kScanBlock), 0,
                      a.stream, ws, chunks);
   hipLaunchKernelGGL(grid_scan_offsets_kernel, dim3((unsigned)a.N, which), dim3(kScanBlock), 0, a.stream, ws, chunks);
   hipLaunchKernelGGL(grid_scan_apply_kernel, dim3((unsigned)chunks, (unsigned)a.N, which), dim3(kScanBlock), 0,
                      a.stream, ws, chunks);
-  PO_BIN(true, false, false, g2, a.p2, a.P2);
-  if (!same) PO_BIN(true, true, false, g1, a.p1, a.P1);
+  if (same) PO_BIN(true, false);
+  else PO_BIN(true, true);
 #undef PO_BIN
 }
 

@@ -56,7 +56,10 @@ template <int KC>
 struct LaneCfg {
   static constexpr bool kUseQueue = KC >= 8;
   static constexpr int kQueueCap = 16;                  // per-lane LDS queue slots (KC = 8 merges the 8 smallest)
-  static constexpr int kGroup = KC >= 8 ? 8 : 4;        // records per group
+#ifndef POINTOPS_LANE_GROUP
+#define POINTOPS_LANE_GROUP 4  // 8 measured 0.776 vs 0.755 ms at cfg2 (K=16), 1.46 vs 1.31 ms at K=32: fewer masked slots
+#endif                         // (a run of ~19 records wastes 1.5 of 4 against 3.5 of 8) beat the fewer, wider groups
+  static constexpr int kGroup = KC >= 8 ? POINTOPS_LANE_GROUP : 4;  // records per group
   static constexpr int kSub = kGroup;                   // candidates between two queue-full checks (whole groups:
                                                         // a check inside the group needs two code paths that merge, and
                                                         // the compiler then rotates the record registers with copies

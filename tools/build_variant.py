@@ -1,7 +1,7 @@
 """Build a tuning variant of libpointops_amd.so: one translation unit recompiled with extra -D flags,
 the other objects reused from the regular build.  Select it at run time with POINTOPS_AMD_LIB=<path>.
 
-  python tools/build_variant.py lpq4 knn_grid.hip -DPOINTOPS_QUAD_LANES=4 -DPOINTOPS_QUAD_FETCH=4
+  python tools/build_variant.py g4 knn_grid_d3.hip -DPOINTOPS_LANE_GROUP=4
   -> pytorch3d_pointops_amd/lib/variants/libpointops_amd_lpq4.so
 """
 import glob
@@ -18,7 +18,8 @@ def main():
     B.build()
     out_dir = os.path.join(B.LIB_DIR, "variants")
     os.makedirs(out_dir, exist_ok=True)
-    obj = os.path.join(B.OBJ_DIR, f"{unit}.{name}.o")
+    os.makedirs(os.path.join(B.OBJ_DIR, "variants"), exist_ok=True)  # (build/variants/ is .gpurunignore'd)
+    obj = os.path.join(B.OBJ_DIR, "variants", f"{unit}.{name}.o")
     subprocess.check_call([B.HIPCC] + B.CXXFLAGS + flags + ["-c", os.path.join(B.CSRC, unit), "-o", obj])
     objs = [o for o in sorted(glob.glob(os.path.join(B.OBJ_DIR, "*.hip.o"))) if os.path.basename(o) != unit + ".o"]
     lib = os.path.join(out_dir, f"libpointops_amd_{name}.so")
