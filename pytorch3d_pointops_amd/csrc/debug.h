@@ -4,6 +4,7 @@
 // default; no knob ever changes results, only which exact path computes them.
 //   knn_generic=1      knn_wide's plain generic kernel instead of its LDS-tiled forms
 //   grid_quad=0|1      force the quad pass of the grid KNN off / on (default: by cloud size)
+//   grid_refine=0      no refined cells (over-full neighbourhoods still go to the box search, over whole cells)
 //   grid_same=0        do not reuse the point sort as the query order when p1 is p2
 //   grid_c_scale=F     multiply the grid KNN's points-per-cell target (sweeps)
 //   ball_grid=0|1      ball query: never / whenever possible through the grid (default: by shape)

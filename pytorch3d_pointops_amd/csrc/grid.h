@@ -27,6 +27,16 @@ struct GridCloud {
   int same;  // 1 = the queries ARE the points (p1 == p2, lengths1 == lengths2): the point sort is the query order
 };
 
+// A REFINED cell: a level-0 cell holding far more points than the target gets its own s x s x s sub-grid over the
+// robust extent (mean +- 2.2 sigma per dimension) of ITS points; the cell's records are re-sorted by sub-cell inside
+// the cell's range of the sorted array.  sub_d(x) = clamp(int((x - lo_d) * scale_d), 0, s - 1): monotone, total.
+struct RefinedCell {
+  int start, count;  // the cell's range of the cloud's sorted records
+  int s;             // sub-cells per dimension
+  int pool_off;      // sub_start table (s^3 + 1 ints, relative to `start`) inside the cloud's pool
+  float lo[3], scale[3];
+};
+
 struct GridWs {
   GridCloud* cloud;   // N
   int* chunk_prefix;  // N + 1     64-query chunks of the clouds before cloud n
@@ -49,6 +59,17 @@ struct GridWs {
   int* rank1;         // N * P1     rank of a query / point inside its bin (many-bin clouds only)
   int* rank2;         // N * P2
   int* grid_flag;     // N          1 = the cloud was searched through its grid (ball query: scan only the list)
+  // refined cells and the box search (grid_refine.hip, knn_grid_box.h)
+  int* refine_ref;    // N * cell_cap   per cell: index of its RefinedCell, or -1
+  RefinedCell* rdesc; // N * rdesc_cap
+  int* rcount;        // N          refined cells of the cloud (may exceed rdesc_cap: clamp)
+  int* pool;          // N * pool_cap   sub_start tables
+  int* pool_top;      // N
+  float4* sorted_tmp; // N * P2     scratch of the in-cell re-sort
+  int* box_count;     // N          queries deferred to the box search
+  int* box_list;      // N * P1
+  int rdesc_cap, pool_cap;
+  float c_target;     // points per cell the grid was sized for
   int cell_cap;
   int ball;           // 0 = KNN (pad rows with idx 0), 1 = ball query (pad with idx -1; clouds without a
                       //     usable grid are left to the scan kernel instead of the query list)
@@ -64,10 +85,29 @@ struct GridBuild {
   bool same;           // p1 and p2 are the same buffer with the same lengths: sort once
 };
 
+constexpr int kRefineMaxS = 32;  // sub-cells per dimension cap (32^3 counters = the LDS of one workgroup)
+
+// a cell is refined when it holds more than this many points; a query leaves the lane search for the box search
+// when its own cell does, or when its 3x3x3 cube holds more than kDeferFactor times that
+__host__ __device__ inline int refine_threshold(float c_target) {
+  const float r = 8.0f * c_target;
+  return r < 48.0f ? 48 : (int)r;
+}
+constexpr int kDeferFactor = 14;
+
+__device__ __forceinline__ int sub_of(float x, float lo, float scale, int s) {
+  const float t = (x - lo) * scale;  // unfused; monotone non-decreasing in x
+  int c = (t < (float)s) ? (int)t : s - 1;
+  if (!(t >= 0.0f)) c = 0;
+  return c;
+}
+
 // workspace layout (grid_build.hip)
 size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, float c_target);
 // bbox, cell size, edge tables, counting sorts of points and queries, chunk prefix; stream-ordered
 int grid_build(const KnnArgs& a, const GridWs& ws, const GridBuild& b);
+// refine over-full cells (grid_refine.hip); stream-ordered behind grid_build
+int grid_refine(const KnnArgs& a, const GridWs& ws, bool enable);
 
 // ---------------------------------------------------------------------------
 // monotone cell function and ordered fp32 keys

@@ -228,6 +228,9 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     ws.fb_count[n] = 0;
     ws.fb2_count[n] = 0;
     ws.fb3_count[n] = 0;
+    ws.rcount[n] = 0;
+    ws.pool_top[n] = 0;
+    ws.box_count[n] = 0;
   }
   __syncthreads();
   if (s_g.use_grid) {
@@ -552,6 +555,17 @@ size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, flo
   w.grid_flag = (int*)take(sizeof(int) * (size_t)N);
   w.rank1 = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.rank2 = (int*)take(sizeof(int) * (size_t)N * (size_t)P2);
+  w.rdesc_cap = (int)(P2 / 48 + 1);  // a refined cell holds more than refine_threshold() >= 48 points
+  w.pool_cap = (int)(4 * P2 + 64);   // sum of (s^3 + 1) <= sum of (8 count / c + 9) over refined cells
+  w.refine_ref = (int*)take(sizeof(int) * (size_t)N * cap);
+  w.rdesc = (RefinedCell*)take(sizeof(RefinedCell) * (size_t)N * (size_t)w.rdesc_cap);
+  w.rcount = (int*)take(sizeof(int) * (size_t)N);
+  w.pool = (int*)take(sizeof(int) * (size_t)N * (size_t)w.pool_cap);
+  w.pool_top = (int*)take(sizeof(int) * (size_t)N);
+  w.sorted_tmp = (float4*)take(sizeof(float4) * (size_t)N * (size_t)P2);
+  w.box_count = (int*)take(sizeof(int) * (size_t)N);
+  w.box_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
+  w.c_target = c;
   w.ball = 0;
   if (ws) *ws = w;
   return off;

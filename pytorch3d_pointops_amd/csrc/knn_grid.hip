@@ -71,6 +71,7 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
   b.same = a.p1 == a.p2 && a.l1 == a.l2 && a.P1 == a.P2 && debug_knob("grid_same", 1) != 0;
   int rc = grid_build(a, ws, b);
   if (rc != POINTOPS_OK) return rc;
+  if ((rc = grid_refine(a, ws, debug_knob("grid_refine", 1) != 0)) != POINTOPS_OK) return rc;
   const int kc = grid_kc(a.K);
   const bool quad = kc <= 32 && grid_quad_mode(a.P1);  // (64-slot lists: four of them do not fit a quad's registers)
   switch (a.D) {
@@ -107,14 +108,14 @@ extern "C" int pointops_knn_grid_fallback_counts(const void* workspace, int64_t 
 }
 
 // grid geometry + fallback counters of the last knn_points_idx call that used `workspace`:
-// stats (N, 8) int32 = G[0], G[1], G[2], ncell, use_grid, uncertified after the lane pass, after the quad pass,
-// sent to the whole-cloud scan
+// stats (N, 10) int32 = G[0], G[1], G[2], ncell, use_grid, uncertified after the lane pass, after the quad + box passes,
+// sent to the whole-cloud scan, deferred to the box search, refined cells
 namespace pointops {
 __global__ void grid_stats_kernel(GridWs ws, int N, int32_t* __restrict__ stats) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const GridCloud g = ws.cloud[n];
-  int32_t* s = stats + (int64_t)n * 8;
+  int32_t* s = stats + (int64_t)n * 10;
   s[0] = g.G[0];
   s[1] = g.G[1];
   s[2] = g.G[2];
@@ -123,6 +124,8 @@ __global__ void grid_stats_kernel(GridWs ws, int N, int32_t* __restrict__ stats)
   s[5] = ws.fb_count[n];
   s[6] = ws.fb3_count[n];
   s[7] = ws.fb2_count[n];
+  s[8] = ws.box_count[n];
+  s[9] = ws.rcount[n];
 }
 }  // namespace pointops
 

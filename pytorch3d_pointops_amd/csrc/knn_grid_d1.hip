@@ -1,5 +1,6 @@
 // knn_grid_d1.hip -- instantiates the grid search kernels (knn_grid_search.h) for D = 1.
 #include "knn_grid_search.h"
+#include "knn_grid_box.h"
 
 namespace pointops {
 

@@ -1,5 +1,6 @@
 // knn_grid_d3.hip -- instantiates the grid search kernels (knn_grid_search.h) for D = 3.
 #include "knn_grid_search.h"
+#include "knn_grid_box.h"
 
 namespace pointops {
 

@@ -66,26 +66,144 @@ struct LaneCfg {
                                                         // behind an s_waitcnt vmcnt(0))
 };
 
-template <int D, int KC, int NORM>
-__global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
-    const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const int* __restrict__ chunk_prefix,
-    const float* __restrict__ edges, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
-    const int* __restrict__ qlist, int* __restrict__ fb_count, int* __restrict__ fb_list,
-    unsigned* __restrict__ fb_kth, int cell_cap, int P1, int P2, int K, int N, int64_t* __restrict__ idxs,
-    float* __restrict__ dists) {
+// ---------------------------------------------------------------------------
+// The walk + selection core shared by the lane search and the box search: the calling lane's runs are the
+// packed words rows[lane + r * 64], r = 0 .. ROWS (first record << kRunBits | length; zero-terminated, slot ROWS
+// is always zero); on return `top` holds the KC best of those records (see the comment above the lane kernel).
+// `s_queue` is the wave's 16 x 64 queue, every slot holding the empty key on entry and on return.
+// ---------------------------------------------------------------------------
+constexpr int kRunBits = 11, kRunMax = (1 << kRunBits) - 1;
+
+template <int D, int KC, int NORM, int ROWS>
+__device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const unsigned* rows, int lane,
+                                          double* s_queue, float qx, float qy, float qz, unsigned thr0,
+                                          TopKF64<KC>& top) {
   using Cfg = LaneCfg<KC>;
   constexpr bool kUseQueue = Cfg::kUseQueue;
   constexpr int kQueueCap = Cfg::kQueueCap;
   constexpr int kSub = Cfg::kSub;
   constexpr int G = Cfg::kGroup;
   constexpr int kGroupBytes = G * 16;
+  double* const qbase = s_queue + lane;
+  int rowi = lane + 2 * kGridWave;  // entry of `rows` after the prefetched one
+  const int rowlast = lane + ROWS * kGridWave;
+  unsigned off;  // byte offset of the lane's next group inside the cloud's record array
+  int rem;       // bytes of the current run from `off` on (<= 0: the run is used up)
+  unsigned nse;  // the lane's next run, read from LDS one switch ahead (its latency stays off the walk)
+  {
+    const unsigned se = rows[lane];
+    off = (se >> kRunBits) * 16u;
+    rem = (int)(se & (unsigned)kRunMax) * 16;
+    nse = rows[lane + kGridWave];
+  }
+  auto advance = [&]() __attribute__((always_inline)) {
+    rem -= kGroupBytes;
+    off += kGroupBytes;
+    if (rem <= 0) {  // next run of this lane (exec-masked; some lane switches in most iterations)
+      off = (nse >> kRunBits) * 16u;
+      rem = (int)(nse & (unsigned)kRunMax) * 16;
+      nse = rows[rowi];
+      rowi = min(rowi + kGridWave, rowlast);
+    }
+  };
+  auto record = [&](unsigned o, int u) __attribute__((always_inline)) -> float4 {
+    return *(const float4*)(spb + o + (unsigned)(16 * u));  // saddr + 32-bit voffset + immediate
+  };
+
+  unsigned thr = thr0;
+  int qn = lane;  // next free slot of the lane's queue (element index into s_queue)
+
+  float4 c[G];
+  int crem = rem;  // validity of the group held in c[]: record u is part of the run iff 16 u < crem
+#pragma unroll
+  for (int u = 0; u < G; ++u) c[u] = record(off, u);
+  // kSub records of the group in c[], starting at u0 (compile-time): distances, then reload the registers
+  // with the NEXT group's records, then the threshold tests
+  auto part = [&](auto u0c) __attribute__((always_inline)) {
+    constexpr int u0 = decltype(u0c)::value;
+    float dd[kSub];
+    int ii[kSub];
+#pragma unroll
+    for (int u = u0; u < u0 + kSub; ++u) {
+      dd[u - u0] = point_dist<D, NORM>(qx, qy, qz, c[u]);
+      ii[u - u0] = __float_as_int(c[u].w);
+    }
+    // the reloads stay BEHIND the distances (hoisted above them, old and new records overlap in lifetime
+    // and the compiler copies four float4 per part to rotate the registers)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = u0; u < u0 + kSub; ++u) c[u] = record(off, u);  // next group's records into the same registers
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < kSub; ++t) {
+      const bool valid = 16 * (u0 + t) < crem;
+      if (kUseQueue) {
+        if (valid && __float_as_uint(dd[t]) <= thr) {
+          s_queue[qn] = TopKF64<KC>::make(dd[t], ii[t]);
+          qn += kGridWave;
+        }
+      } else if (valid && __float_as_uint(dd[t]) <= min(top.worst_bits(), thr0)) {
+        top.insert(TopKF64<KC>::make(dd[t], ii[t]));
+      }
+    }
+  };
+  if constexpr (kUseQueue) {
+    // The sorted list lives in 2 KC registers that only a flush touches: the walk is an INNER loop that
+    // never names them (a flush inside the walk loop made the compiler shuffle the whole list between
+    // two register sets on every iteration), left whenever some lane's queue could overflow in the next group.
+    static_assert(G == kSub && kQueueCap >= 2 * kSub, "queue geometry");
+    bool more = __any(crem > 0);
+    while (more) {
+      bool full;
+      do {
+        advance();  // (off, rem) now describe the NEXT group
+        part(std::integral_constant<int, 0>{});
+        crem = rem;
+        more = __any(crem > 0);
+        full = __any(qn > lane + (kQueueCap - kSub) * kGridWave);
+      } while (!full && more);
+      // merge: queue -> sorted network -> list
+      double qk[kQueueCap];
+#pragma unroll
+      for (int t = 0; t < kQueueCap; ++t) qk[t] = qbase[t * kGridWave];  // free slots hold the empty key
+#pragma unroll
+      for (int t = 0; t < kQueueCap; ++t) qbase[t * kGridWave] = TopKF64<KC>::empty();
+      bitonic_sort<kQueueCap>(qk);
+      constexpr int kMeet = KC < kQueueCap ? KC : kQueueCap;
+#pragma unroll
+      for (int t = 0; t < kMeet; ++t) top.key[KC - 1 - t] = kmin(top.key[KC - 1 - t], qk[t]);  // list slot KC-1-t meets queue entry t
+      bitonic_merge<KC>(top.key);
+      qn = lane;
+      thr = min(top.worst_bits(), thr0);
+    }
+  } else {
+    static_assert(G == kSub, "direct-insert variants take one part per group");
+    while (__any(crem > 0)) {
+      advance();
+      part(std::integral_constant<int, 0>{});
+      crem = rem;
+    }
+  }
+}
+
+template <int D, int KC, int NORM>
+__global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
+    const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const int* __restrict__ chunk_prefix,
+    const float* __restrict__ edges, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
+    const int* __restrict__ qlist, int* __restrict__ fb_count, int* __restrict__ fb_list,
+    unsigned* __restrict__ fb_kth, int* __restrict__ box_count, int* __restrict__ box_list, int defer_limit,
+    int cell_cap, int P1, int P2, int K, int N, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+  using Cfg = LaneCfg<KC>;
+  constexpr bool kUseQueue = Cfg::kUseQueue;
+  constexpr int kQueueCap = Cfg::kQueueCap;
+  constexpr int kSub = Cfg::kSub;
+  constexpr int G = Cfg::kGroup;
   static_assert(G % kSub == 0 && G <= kSortedPad, "group geometry");
   __shared__ double s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
   // per-lane list of its non-empty runs, one word each: first record << 11 | length (<= 2047; a lane with a longer
   // run -- an over-full cell -- leaves its query to the fallback passes), then zeros.  Packed so that a wave needs
   // 2.5 KB instead of 5 KB of LDS: with the 8 KB queue that is 15 instead of 12 waves per CU.
   __shared__ unsigned s_rows[kLaneRows + 1][kGridWave];
-  constexpr int kRunBits = 11, kRunMax = (1 << kRunBits) - 1;
 
   const int lane = threadIdx.x;
   const int total = chunk_prefix[N];
@@ -93,7 +211,6 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
 #pragma unroll
     for (int t = 0; t < kQueueCap; ++t) s_queue[t * kGridWave + lane] = TopKF64<KC>::empty();
   }
-  double* const qbase = s_queue + lane;
   unsigned* const rows = &s_rows[0][0];
   // XCD-aware item order: workgroup b runs on XCD b % 8 (round-robin dispatch), and the chunks are
   // sorted by (cloud, cell).  Each XCD walks its own contiguous eighth of the chunk list, so the
@@ -137,9 +254,12 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     const unsigned thr0 = seed_threshold(lb, whole);
 
     // the lane's non-empty runs, own row first (near-first order tightens the thresholds early)
+    // A lane whose cube is over-full (a run longer than the packed length field, or more than `defer_limit`
+    // records in all) does not walk: its query goes to the box search over the refined cells (knn_grid_box.h).
     bool overlong = false;
     {
       int cnt = 0;  // rows written so far, as an element offset into s_rows
+      int total = 0;
 #pragma unroll
       for (int r = 0; r < kLaneRows; ++r) {
         constexpr int kDz[kLaneRows] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
@@ -150,120 +270,23 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
           const int s = cstart[rowbase + X0], e = cstart[rowbase + X1 + 1];
           if (e > s) {
             overlong = overlong || e - s > kRunMax;
+            total += e - s;
             rows[lane + cnt] = ((unsigned)s << kRunBits) | (unsigned)min(e - s, kRunMax);
             cnt += kGridWave;
           }
         }
       }
-      if (overlong) cnt = 0;  // this lane does not walk: its query goes to the fallback passes
+      overlong = overlong || total > defer_limit;
+      if (overlong) cnt = 0;  // this lane does not walk
       // terminators: every slot from the lane's count on (a finished lane keeps reading 0)
 #pragma unroll
       for (int r = 0; r <= kLaneRows; ++r) {
         if (r * kGridWave >= cnt) s_rows[r][lane] = 0u;
       }
     }
-    int rowi = lane + 2 * kGridWave;  // entry of `rows` after the prefetched one
-    const int rowlast = lane + kLaneRows * kGridWave;
-    unsigned off;  // byte offset of the lane's next group inside the cloud's record array
-    int rem;       // bytes of the current run from `off` on (<= 0: the run is used up)
-    unsigned nse;  // the lane's next run, read from LDS one switch ahead (its latency stays off the walk)
-    {
-      const unsigned se = rows[lane];
-      off = (se >> kRunBits) * 16u;
-      rem = (int)(se & (unsigned)kRunMax) * 16;
-      nse = rows[lane + kGridWave];
-    }
-    auto advance = [&]() __attribute__((always_inline)) {
-      rem -= kGroupBytes;
-      off += kGroupBytes;
-      if (rem <= 0) {  // next run of this lane (exec-masked; some lane switches in most iterations)
-        off = (nse >> kRunBits) * 16u;
-        rem = (int)(nse & (unsigned)kRunMax) * 16;
-        nse = rows[rowi];
-        rowi = min(rowi + kGridWave, rowlast);
-      }
-    };
-    const char* __restrict__ spb = (const char*)sp;
-    auto record = [&](unsigned o, int u) __attribute__((always_inline)) -> float4 {
-      return *(const float4*)(spb + o + (unsigned)(16 * u));  // saddr + 32-bit voffset + immediate
-    };
-
     TopKF64<KC> top;
     top.init();
-    unsigned thr = thr0;
-    int qn = lane;  // next free slot of the lane's queue (element index into s_queue)
-
-    float4 c[G];
-    int crem = rem;  // validity of the group held in c[]: record u is part of the run iff 16 u < crem
-#pragma unroll
-    for (int u = 0; u < G; ++u) c[u] = record(off, u);
-    // kSub records of the group in c[], starting at u0 (compile-time): distances, then reload the registers
-    // with the NEXT group's records, then the threshold tests
-    auto part = [&](auto u0c) __attribute__((always_inline)) {
-      constexpr int u0 = decltype(u0c)::value;
-      float dd[kSub];
-      int ii[kSub];
-#pragma unroll
-      for (int u = u0; u < u0 + kSub; ++u) {
-        dd[u - u0] = point_dist<D, NORM>(qx, qy, qz, c[u]);
-        ii[u - u0] = __float_as_int(c[u].w);
-      }
-      // the reloads stay BEHIND the distances (hoisted above them, old and new records overlap in lifetime
-      // and the compiler copies four float4 per part to rotate the registers)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = u0; u < u0 + kSub; ++u) c[u] = record(off, u);  // next group's records into the same registers
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < kSub; ++t) {
-        const bool valid = 16 * (u0 + t) < crem;
-        if (kUseQueue) {
-          if (valid && __float_as_uint(dd[t]) <= thr) {
-            s_queue[qn] = TopKF64<KC>::make(dd[t], ii[t]);
-            qn += kGridWave;
-          }
-        } else if (valid && __float_as_uint(dd[t]) <= min(top.worst_bits(), thr0)) {
-          top.insert(TopKF64<KC>::make(dd[t], ii[t]));
-        }
-      }
-    };
-    if constexpr (kUseQueue) {
-      // The sorted list lives in 2 KC registers that only a flush touches: the walk is an INNER loop that
-      // never names them (a flush inside the walk loop made the compiler shuffle the whole list between
-      // two register sets on every iteration), left whenever some lane's queue could overflow in the next group.
-      static_assert(G == kSub && kQueueCap >= 2 * kSub, "queue geometry");
-      bool more = __any(crem > 0);
-      while (more) {
-        bool full;
-        do {
-          advance();  // (off, rem) now describe the NEXT group
-          part(std::integral_constant<int, 0>{});
-          crem = rem;
-          more = __any(crem > 0);
-          full = __any(qn > lane + (kQueueCap - kSub) * kGridWave);
-        } while (!full && more);
-        // merge: queue -> sorted network -> list
-        double qk[kQueueCap];
-#pragma unroll
-        for (int t = 0; t < kQueueCap; ++t) qk[t] = qbase[t * kGridWave];  // free slots hold the empty key
-#pragma unroll
-        for (int t = 0; t < kQueueCap; ++t) qbase[t * kGridWave] = TopKF64<KC>::empty();
-        bitonic_sort<kQueueCap>(qk);
-        constexpr int kMeet = KC < kQueueCap ? KC : kQueueCap;
-#pragma unroll
-        for (int t = 0; t < kMeet; ++t) top.key[KC - 1 - t] = kmin(top.key[KC - 1 - t], qk[t]);  // list slot KC-1-t meets queue entry t
-        bitonic_merge<KC>(top.key);
-        qn = lane;
-        thr = min(top.worst_bits(), thr0);
-      }
-    } else {
-      static_assert(G == kSub, "direct-insert variants take one part per group");
-      while (__any(crem > 0)) {
-        advance();
-        part(std::integral_constant<int, 0>{});
-        crem = rem;
-      }
-    }
+    lane_walk<D, KC, NORM, kLaneRows>((const char*)sp, rows, lane, s_queue, qx, qy, qz, thr0, top);
 
     const unsigned kth_bits = top.kth_bits(K);  // the K-th best, not the list's last slot
     const bool full = kth_bits < 0x7f800000u;
@@ -272,6 +295,9 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
       if (ok) {
         const int64_t row = (int64_t)n * P1 + qi;
         write_row_f64<KC>(top, K, g.len2, idxs + row * K, dists + row * K);
+      } else if (overlong) {
+        const int pos = atomicAdd(box_count + n, 1);
+        box_list[(int64_t)n * P1 + pos] = qi;
       } else {
         const int pos = atomicAdd(fb_count + n, 1);
         fb_list[(int64_t)n * P1 + pos] = qi;
@@ -305,6 +331,7 @@ constexpr int kQuadLanes = 4;  // lanes per query
 constexpr int kQuadRows = (25 + kQuadLanes - 1) / kQuadLanes;
 constexpr int kQuadQueries = kGridWave / kQuadLanes;
 constexpr int kQuadFetch = 8;  // gathers in flight per lane and pipeline stage
+constexpr int kQuadMaxRecords = 1024;  // per lane of the quad
 __device__ constexpr signed char kQuadDy[32] = {0, 0, 0, -1, 1, -1, -1, 1, 1, 0, 0, -2, 2, -1, 1, -1, 1, -2, -2, 2, 2, -2, -2, 2, 2, 0, 0, 0, 0, 0, 0, 0};
 __device__ constexpr signed char kQuadDz[32] = {0, -1, 1, 0, 0, -1, 1, -1, 1, -2, 2, 0, 0, -2, -2, 2, 2, -1, 1, -1, 1, -2, 2, -2, 2, 0, 0, 0, 0, 0, 0, 0};
 
@@ -399,6 +426,19 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
       }
       s_rows[j][lane] = se;
     }
+    // a quad whose cube holds an over-full cell does not walk it lane by lane: the wave-per-query search
+    // (64 lanes on one candidate stream) takes the query
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < kQuadRows; ++j) mine += s_rows[j][lane].y - s_rows[j][lane].x;
+    int bigq = mine > kQuadMaxRecords ? 1 : 0;  // OR over the quad, outside any divergent branch (a DPP read of an
+    bigq |= __builtin_amdgcn_mov_dpp(bigq, kDppXor1, 0xf, 0xf, true);  // inactive lane returns 0)
+    bigq |= __builtin_amdgcn_mov_dpp(bigq, kDppXor2, 0xf, 0xf, true);
+    const bool big = bigq != 0;
+    if (big) {
+#pragma unroll
+      for (int j = 0; j < kQuadRows; ++j) s_rows[j][lane] = make_int2(0, 0);
+    }
     int r = 0;
     int cur = s_rows[0][lane].x, end = s_rows[0][lane].y;
     auto next_record = [&]() -> int {
@@ -471,7 +511,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
 
     const unsigned kth_bits = top.kth_bits(K);  // the K-th best, not the list's last slot
     const bool full = kth_bits < 0x7f800000u;
-    const bool ok = whole || (full && __uint_as_float(kth_bits) < lb);
+    const bool ok = !big && (whole || (full && __uint_as_float(kth_bits) < lb));
     if (active && sub == 0) {
       if (ok) {
         const int64_t row = (int64_t)n * P1 + qi;
@@ -496,7 +536,9 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
 // ---------------------------------------------------------------------------
 constexpr int kWaveKernelBlock = 256;
 constexpr int kWaveKernelWgsPerCloud = 64;
-constexpr int kWaveRegionCap = 16384;
+constexpr int kWaveRegionCap = 1 << 22;  // records: in effect the wave search always finishes (a cube that holds an
+                                         // over-full cell is still 64 lanes on one coalesced stream; the whole-cloud
+                                         // scan it used to give up to after 16 384 records runs ONE lane per query)
 constexpr int kWaveRows = 96;  // (2r+1)^2 rows for r = 2 (25) and r = 4 (81)
 
 template <int D, int KC, int NORM>
@@ -647,12 +689,16 @@ __global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
 // launches of one (D, NORM): lane search, then the exact fallbacks for what it could not certify
 // ---------------------------------------------------------------------------
 template <int D, int KC, int NORM>
+static void launch_grid_box(const KnnArgs& a, const GridWs& ws, bool quad);  // knn_grid_box.h
+
+template <int D, int KC, int NORM>
 static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
   const int wgs = 256 * 32;  // one wave64 per workgroup, up to 32 waves per CU resident
   hipLaunchKernelGGL((knn_grid_lane_kernel<D, KC, NORM>), dim3((unsigned)wgs), dim3(kGridWave), 0, a.stream, a.p1,
                      (const GridCloud*)ws.cloud, (const int*)ws.chunk_prefix, (const float*)ws.edges,
                      (const int*)ws.cell_start, (const float4*)ws.sorted, (const int*)ws.qlist, ws.fb_count,
-                     ws.fb_list, ws.fb_kth, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
+                     ws.fb_list, ws.fb_kth, ws.box_count, ws.box_list, kDeferFactor * refine_threshold(ws.c_target),
+                     ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
   if constexpr (KC <= 32) if (quad) {
     int64_t wx = a.P1 / (32 * kQuadQueries);  // a few % of a cloud arrive here
     wx = wx < 8 ? 8 : wx > 4096 ? 4096 : wx;
@@ -662,6 +708,7 @@ static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
                        (const unsigned*)ws.fb_kth, ws.fb3_count, ws.fb3_list, ws.cell_cap, a.P1, a.P2, a.K, a.idxs,
                        a.dists);
   }
+  launch_grid_box<D, KC, NORM>(a, ws, quad);  // over-full neighbourhoods (appends what it cannot certify)
   hipLaunchKernelGGL((knn_grid_wave_kernel<D, KC, NORM>), dim3(kWaveKernelWgsPerCloud, (unsigned)a.N),
                      dim3(kWaveKernelBlock), 0, a.stream, a.p1, (const GridCloud*)ws.cloud, (const float*)ws.edges,
                      (const int*)ws.cell_start, (const float4*)ws.sorted,

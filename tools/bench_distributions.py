@@ -45,7 +45,8 @@ def main():
         print(json.dumps(dict(op=f"knn_points B={B} N=M={P} K={K}", dist=name, median_ms=ms, min_ms=mn,
                               vs_uniform=ms / base["knn"], cells_cloud0=st[0, :3].astype(int).tolist(),
                               grid_used=int(st[:, 4].sum()), uncertified_lane=st[:, 5].mean(),
-                              uncertified_quad=st[:, 6].mean(), whole_cloud_scan=st[:, 7].mean())), flush=True)
+                              uncertified_quad_box=st[:, 6].mean(), whole_cloud_scan=st[:, 7].mean(),
+                              deferred_to_box=st[:, 8].mean(), refined_cells=st[:, 9].mean())), flush=True)
         # self-query (p1 is p2): one sort
         ms_s, mn_s = timeit(lambda: _C.knn_points_idx(p2, p2, L, L, 2, K, -1), warmup=2, iters=7)
         print(json.dumps(dict(op=f"knn_points SELF B={B} N={P} K={K}", dist=name, median_ms=ms_s, min_ms=mn_s,
