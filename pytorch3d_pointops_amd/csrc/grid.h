@@ -87,13 +87,16 @@ struct GridBuild {
 
 constexpr int kRefineMaxS = 32;  // sub-cells per dimension cap (32^3 counters = the LDS of one workgroup)
 
-// a cell is refined when it holds more than this many points; a query leaves the lane search for the box search
-// when its own cell does, or when its 3x3x3 cube holds more than kDeferFactor times that
+// A query leaves the lane search for the box search when its 3x3x3 cube holds more than kDeferFactor x
+// refine_threshold() records (~4x what a uniform cloud gives it); a cell is refined when it holds more than
+// refine_threshold() points -- a quarter of that limit, so a cube is only ever over-full through cells that are
+// refined or through many moderately full ones (which the box search, with its smaller box, walks whole).
+// (Refining from 8x the target on cost the sphere-surface cloud 0.15 ms of sub-sorts that no query used.)
 __host__ __device__ inline int refine_threshold(float c_target) {
-  const float r = 8.0f * c_target;
-  return r < 48.0f ? 48 : (int)r;
+  const float r = 28.0f * c_target;
+  return r < 64.0f ? 64 : (int)r;
 }
-constexpr int kDeferFactor = 14;
+constexpr int kDeferFactor = 4;
 
 __device__ __forceinline__ int sub_of(float x, float lo, float scale, int s) {
   const float t = (x - lo) * scale;  // unfused; monotone non-decreasing in x

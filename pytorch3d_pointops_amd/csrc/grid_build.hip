@@ -555,7 +555,7 @@ size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, flo
   w.grid_flag = (int*)take(sizeof(int) * (size_t)N);
   w.rank1 = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.rank2 = (int*)take(sizeof(int) * (size_t)N * (size_t)P2);
-  w.rdesc_cap = (int)(P2 / 48 + 1);  // a refined cell holds more than refine_threshold() >= 48 points
+  w.rdesc_cap = (int)(P2 / 64 + 1);  // a refined cell holds more than refine_threshold() >= 64 points
   w.pool_cap = (int)(4 * P2 + 64);   // sum of (s^3 + 1) <= sum of (8 count / c + 9) over refined cells
   w.refine_ref = (int*)take(sizeof(int) * (size_t)N * cap);
   w.rdesc = (RefinedCell*)take(sizeof(RefinedCell) * (size_t)N * (size_t)w.rdesc_cap);

@@ -10,7 +10,7 @@
 // dimension, and since fp32 subtraction is monotone its COMPUTED |q_d - u_d| is >= fl(q_d - a_d) resp.
 // fl(b_d - q_d): the certification bound is the minimum of those six face terms (squared for the L2 norm) -- the
 // same argument as the cube faces of the lane search.  kth < bound (strict) => the list is exact; otherwise the
-// radius grows (x 1.8, up to three attempts), then the query goes to the expanding wave search.
+// radius grows (x 1.6, up to five attempts), then the query goes to the expanding wave search.
 // A refined cell that the box covers in many sub-rows is taken as ONE run (visiting more points is always allowed).
 // The walk and the selection are the lane search's (lane_walk).
 #pragma once
@@ -18,8 +18,11 @@
 
 namespace pointops {
 
-constexpr int kBoxRows = 39;      // run slots per lane (+ 1 terminator): 40 words x 64 lanes = 10 KB
-constexpr int kBoxAttempts = 3;
+constexpr int kBoxRows = 39;      // run slots per lane (+ 1 terminator): 40 words x 64 lanes = 10 KB (23 slots: more waves, but
+                                  // twice the overflows to the wave search on the u^4 cloud: 6.4 -> 8.4 ms)
+constexpr int kBoxAttempts = 5;      // radii r0, 1.6 r0, ... ; r0 = the density estimate inside a refined cell, 0.35 of it next
+                                     // to one (the estimate of a sparse cell is far beyond the near face of a dense
+                                     // neighbour: small steps find the radius where the box clips a corner of it)
 constexpr int kBoxSubRowsMax = 12;  // sub-rows of one refined cell a box may enumerate before taking the cell whole
 constexpr int kBoxMaxRecords = 3072;  // a lane never walks more than this: a bigger candidate set (a box that covers a
                                       // dense cell from outside) belongs to the wave-per-query search, whose 64 lanes
@@ -83,6 +86,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_box_kernel(
       const float ball = 2.5f * (float)K * vol / cntf;  // volume expected to hold 2.5 K points
       r = D == 3 ? cbrtf(ball * 0.2387f) : D == 2 ? sqrtf(ball * 0.3183f) : ball * 0.5f;
       if (!(r > 0.0f) || !(r <= FLT_MAX)) r = h;
+      if (ref < 0) r *= 0.35f;
     }
 
     bool done = !active;  // nothing (more) to do for this lane
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_box_kernel(
         }
       }
       if (overflow) done = true;  // too many runs for the list: leave it to the fallback below
-      r *= 1.8f;
+      r *= 1.6f;
     }
     if (active && !certified) {  // expanding wave search (knn_grid_wave_kernel), through the list it reads
       const int pos = atomicAdd(out_count + n, 1);

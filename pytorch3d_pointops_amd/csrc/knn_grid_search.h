@@ -365,8 +365,8 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
     const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const float* __restrict__ edges,
     const int* __restrict__ cell_start, const float4* __restrict__ sorted, const int* __restrict__ fb_count,
     const int* __restrict__ fb_list, const unsigned* __restrict__ fb_kth, int* __restrict__ fb3_count,
-    int* __restrict__ fb3_list, int cell_cap, int P1, int P2, int K, int64_t* __restrict__ idxs,
-    float* __restrict__ dists) {
+    int* __restrict__ fb3_list, int* __restrict__ box_count, int* __restrict__ box_list, int cell_cap, int P1, int P2,
+    int K, int64_t* __restrict__ idxs, float* __restrict__ dists) {
   constexpr bool kUseQueue = KC >= 8;
   constexpr int kQueueCap = KC < 16 ? KC : 16;
   constexpr int kSub = 4;
@@ -426,8 +426,8 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
       }
       s_rows[j][lane] = se;
     }
-    // a quad whose cube holds an over-full cell does not walk it lane by lane: the wave-per-query search
-    // (64 lanes on one candidate stream) takes the query
+    // a quad whose cube holds an over-full cell does not walk it lane by lane: the box search (which sees the
+    // refined cell's inside) takes the query
     int mine = 0;
 #pragma unroll
     for (int j = 0; j < kQuadRows; ++j) mine += s_rows[j][lane].y - s_rows[j][lane].x;
@@ -516,6 +516,9 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
       if (ok) {
         const int64_t row = (int64_t)n * P1 + qi;
         write_row_f64<KC>(top, K, g.len2, idxs + row * K, dists + row * K);
+      } else if (big) {  // an over-full cell in the cube: the box search knows its inside
+        const int pos = atomicAdd(box_count + n, 1);
+        box_list[(int64_t)n * P1 + pos] = qi;
       } else {
         const int pos = atomicAdd(fb3_count + n, 1);
         fb3_list[(int64_t)n * P1 + pos] = qi;
@@ -535,7 +538,8 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
 // case the query goes to the whole-cloud lane-per-query scan (far-away queries).
 // ---------------------------------------------------------------------------
 constexpr int kWaveKernelBlock = 256;
-constexpr int kWaveKernelWgsPerCloud = 64;
+constexpr int kWaveKernelWgsPerCloud = 256;  // x 4 waves: the pass is latency-bound per query, so one query per wave
+                                             // wherever a cloud sends it up to ~1000 (64: 2.1 -> ms at 761 queries per cloud)
 constexpr int kWaveRegionCap = 1 << 22;  // records: in effect the wave search always finishes (a cube that holds an
                                          // over-full cell is still 64 lanes on one coalesced stream; the whole-cloud
                                          // scan it used to give up to after 16 384 records runs ONE lane per query)
@@ -585,18 +589,20 @@ __global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
       int scanned = 0;
       bool giveup = false;
       const int ny = Y1 - Y0 + 1, nrows = ny * (Z1 - Z0 + 1);
-      if (nrows <= kWaveRows) {
-        // Small cubes (r = 2, 4): latency-bound if walked row by row (two dependent scalar loads
-        // per row, then one load per lane).  Instead the lanes fetch all row bounds at once,
-        // a wave scan turns them into a flat record stream, and every lane then owns the
-        // records lane, lane+64, ... with four loads in flight.
-        int* __restrict__ rs = s_rowsrc[wslot];
-        int* __restrict__ ro = s_rowoff[wslot];
-        for (int r0 = 0; r0 < nrows; r0 += kWave) {
+      // Row by row the scan is latency-bound (two dependent scalar loads per row, then one load per lane).
+      // Instead the lanes fetch the bounds of up to kWaveRows rows at once, a wave scan turns them into a flat
+      // record stream, and every lane owns the records lane, lane + 64, ... with eight loads in flight; bigger
+      // cubes (r >= 8) repeat that per block of rows.
+      int* __restrict__ rs = s_rowsrc[wslot];
+      int* __restrict__ ro = s_rowoff[wslot];
+      for (int rb = 0; rb < nrows && !giveup; rb += kWaveRows) {
+        const int nblk = min(kWaveRows, nrows - rb);
+        int T = 0;
+        for (int r0 = 0; r0 < nblk; r0 += kWave) {
           const int rr = r0 + lane;
           int len_r = 0, src = 0;
-          if (rr < nrows) {
-            const int z = Z0 + rr / ny, y = Y0 + rr % ny;
+          if (rr < nblk) {
+            const int z = Z0 + (rb + rr) / ny, y = Y0 + (rb + rr) % ny;
             const int rowbase = (z * g.G[1] + y) * g.G[0];
             src = cstart[rowbase + X0];
             len_r = cstart[rowbase + X1 + 1] - src;
@@ -607,43 +613,34 @@ __global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
             const int v = __shfl_up(inc, off, kWave);
             if (lane >= off) inc += v;
           }
-          if (rr < nrows) {
+          if (rr < nblk) {
             rs[rr] = src;
-            ro[rr + 1] = scanned + inc;
+            ro[rr + 1] = T + inc;
           }
-          scanned += __shfl(inc, kWave - 1, kWave);
+          T += __shfl(inc, kWave - 1, kWave);
         }
         if (lane == 0) ro[0] = 0;
-        const int T = scanned;
-        if (!whole && T > kWaveRegionCap) {
+        scanned += T;
+        if (!whole && scanned > kWaveRegionCap) {
           giveup = true;
-        } else {
-          int rrow = 0;
-          for (int t0 = lane; t0 < T; t0 += 4 * kWave) {
-            float4 c[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int t = t0 + u * kWave;
-              const float qnan = __uint_as_float(0x7fc00000u);
-              c[u] = make_float4(qnan, qnan, qnan, 0.f);
-              if (t < T) {
-                while (ro[rrow + 1] <= t) ++rrow;
-                c[u] = sp[rs[rrow] + (t - ro[rrow])];
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) consider(c[u]);
-          }
+          break;
         }
-      } else {
-        for (int z = Z0; z <= Z1 && !giveup; ++z) {
-          for (int y = Y0; y <= Y1; ++y) {
-            const int rowbase = (z * g.G[1] + y) * g.G[0];
-            const int s = cstart[rowbase + X0], e = cstart[rowbase + X1 + 1];
-            for (int j = s + lane; j < e; j += kWave) consider(sp[j]);
-            scanned += e - s;
+        int rrow = 0;
+        constexpr int kInFlight = 8;  // loads per lane and step
+        for (int t0 = lane; t0 < T; t0 += kInFlight * kWave) {
+          float4 c[kInFlight];
+#pragma unroll
+          for (int u = 0; u < kInFlight; ++u) {
+            const int t = t0 + u * kWave;
+            const float qnan = __uint_as_float(0x7fc00000u);
+            c[u] = make_float4(qnan, qnan, qnan, 0.f);
+            if (t < T) {
+              while (ro[rrow + 1] <= t) ++rrow;
+              c[u] = sp[rs[rrow] + (t - ro[rrow])];
+            }
           }
-          if (!whole && scanned > kWaveRegionCap) giveup = true;
+#pragma unroll
+          for (int u = 0; u < kInFlight; ++u) consider(c[u]);
         }
       }
       if (giveup) {
@@ -705,8 +702,8 @@ static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
     hipLaunchKernelGGL((knn_grid_quad_kernel<D, KC, NORM>), dim3((unsigned)wx, (unsigned)a.N), dim3(kGridWave), 0,
                        a.stream, a.p1, (const GridCloud*)ws.cloud, (const float*)ws.edges, (const int*)ws.cell_start,
                        (const float4*)ws.sorted, (const int*)ws.fb_count, (const int*)ws.fb_list,
-                       (const unsigned*)ws.fb_kth, ws.fb3_count, ws.fb3_list, ws.cell_cap, a.P1, a.P2, a.K, a.idxs,
-                       a.dists);
+                       (const unsigned*)ws.fb_kth, ws.fb3_count, ws.fb3_list, ws.box_count, ws.box_list, ws.cell_cap, a.P1,
+                       a.P2, a.K, a.idxs, a.dists);
   }
   launch_grid_box<D, KC, NORM>(a, ws, quad);  // over-full neighbourhoods (appends what it cannot certify)
   hipLaunchKernelGGL((knn_grid_wave_kernel<D, KC, NORM>), dim3(kWaveKernelWgsPerCloud, (unsigned)a.N),
