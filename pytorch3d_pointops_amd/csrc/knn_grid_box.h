@@ -18,12 +18,13 @@
 
 namespace pointops {
 
-constexpr int kBoxRows = 39;      // run slots per lane (+ 1 terminator): 40 words x 64 lanes = 10 KB (23 slots: more waves, but
+constexpr int kBoxRows = 47;      // run slots per lane (+ 1 terminator): 48 words x 64 lanes = 12 KB (23 slots: more waves, but
                                   // twice the overflows to the wave search on the u^4 cloud: 6.4 -> 8.4 ms)
 constexpr int kBoxAttempts = 5;      // radii r0, 1.6 r0, ... ; r0 = the density estimate inside a refined cell, 0.35 of it next
                                      // to one (the estimate of a sparse cell is far beyond the near face of a dense
                                      // neighbour: small steps find the radius where the box clips a corner of it)
-constexpr int kBoxSubRowsMax = 12;  // sub-rows of one refined cell a box may enumerate before taking the cell whole
+constexpr int kBoxSubRowsMax = 36;  // sub-rows of one refined cell a box may enumerate before taking the cell whole (a query
+                                    // at a corner of a cluster needs its third radius: 5-6 sub-cells per dimension)
 constexpr int kBoxMaxRecords = 3072;  // a lane never walks more than this: a bigger candidate set (a box that covers a
                                       // dense cell from outside) belongs to the wave-per-query search, whose 64 lanes
                                       // share it -- one lane walking 32 k records holds its whole wave for milliseconds
