@@ -341,6 +341,7 @@ int ball_grid_run(const KnnArgs& a, float radius, void* workspace, const int** f
   // measured crossover (grid wins where K len2 / (E max(E, K)) > ~4-7), profiles/r01_ball_crossover.txt
   b.ball_factor = (float)debug_knob_f("ball_factor", 5.0);
   b.same = a.p1 == a.p2 && a.l1 == a.l2 && a.P1 == a.P2 && debug_knob("grid_same", 1) != 0;
+  b.refine = -1;
   const int rc = grid_build(a, ws, b);
   if (rc != POINTOPS_OK) return rc;
   const int wgs = 256 * 32;

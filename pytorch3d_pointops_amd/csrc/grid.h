@@ -83,6 +83,8 @@ struct GridBuild {
   int ball_K;
   float ball_factor;
   bool same;           // p1 and p2 are the same buffer with the same lengths: sort once
+  int refine;          // -1: no refined-cell bookkeeping (ball query); 0: every cell marked unrefined; 1: over-full
+                       // cells get a descriptor + table during the scan (grid_refine() then builds their sub-grids)
 };
 
 constexpr int kRefineMaxS = 32;  // sub-cells per dimension cap (32^3 counters = the LDS of one workgroup)
@@ -109,8 +111,8 @@ __device__ __forceinline__ int sub_of(float x, float lo, float scale, int s) {
 size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, float c_target);
 // bbox, cell size, edge tables, counting sorts of points and queries, chunk prefix; stream-ordered
 int grid_build(const KnnArgs& a, const GridWs& ws, const GridBuild& b);
-// refine over-full cells (grid_refine.hip); stream-ordered behind grid_build
-int grid_refine(const KnnArgs& a, const GridWs& ws, bool enable);
+// build the sub-grids of the cells grid_build marked (grid_refine.hip); stream-ordered behind grid_build
+int grid_refine(const KnnArgs& a, const GridWs& ws);
 
 // ---------------------------------------------------------------------------
 // monotone cell function and ordered fp32 keys

@@ -472,7 +472,9 @@ __global__ __launch_bounds__(kScanBlock) void grid_scan_offsets_kernel(GridWs ws
   if (len == 0 && tid == 0 && ws.cloud[n].use_grid) start[0] = 0;
 }
 
-__global__ __launch_bounds__(kScanBlock) void grid_scan_apply_kernel(GridWs ws, int chunks) {
+// `refine` != 0: the pass over the point cells also marks the over-full ones for refinement (grid_refine.hip):
+// a descriptor and a sub_start table from the cloud's pool, the sub-grid itself is built by refine_build.
+__global__ __launch_bounds__(kScanBlock) void grid_scan_apply_kernel(GridWs ws, int chunks, int refine) {
   __shared__ int s_red[kScanBlock / kWave];
   const int n = blockIdx.y, which = blockIdx.z, chunk = blockIdx.x;
   int *count, *start, len;
@@ -508,6 +510,28 @@ __global__ __launch_bounds__(kScanBlock) void grid_scan_apply_kernel(GridWs ws, 
   for (int r = 0; r < 4; ++r) {
     if (i0 + r < len) {
       start[i0 + r] = run;
+      if (which == 0 && refine >= 0) {
+        int ref = -1;
+        if (refine > 0 && c[r] > refine_threshold(ws.c_target)) {
+          int s = (int)ceilf(cbrtf((float)c[r] / ws.c_target));
+          s = s < 2 ? 2 : (s > kRefineMaxS ? kRefineMaxS : s);
+          const int cells = s * s * s + 1;
+          const int idx = atomicAdd(ws.rcount + n, 1);
+          if (idx < ws.rdesc_cap) {
+            RefinedCell d{};  // count == 0: a descriptor without a table (pool exhausted), skipped by refine_build
+            const int off = atomicAdd(ws.pool_top + n, cells);
+            if (off + cells <= ws.pool_cap) {
+              d.start = run;
+              d.count = c[r];
+              d.s = s;
+              d.pool_off = off;
+              ref = idx;
+            }
+            ws.rdesc[(int64_t)n * ws.rdesc_cap + idx] = d;
+          }
+        }
+        ws.refine_ref[(int64_t)n * ws.cell_cap + i0 + r] = ref;
+      }
       run += c[r];
       count[i0 + r] = 0;
     }
@@ -572,7 +596,7 @@ size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, flo
 }
 
 template <int D>
-static void build_d(const KnnArgs& a, const GridWs& ws, bool same) {
+static void build_d(const KnnArgs& a, const GridWs& ws, bool same, int refine) {
   const int chunks = (ws.cell_cap + kScanChunk - 1) / kScanChunk;
   const unsigned which = same ? 1u : 2u;  // points only / points and queries
   const dim3 gb((unsigned)ceil_div(same ? a.P2 : (a.P2 > a.P1 ? a.P2 : a.P1), kBinTile), (unsigned)a.N, which);
@@ -585,7 +609,7 @@ static void build_d(const KnnArgs& a, const GridWs& ws, bool same) {
                      a.stream, ws, chunks);
   hipLaunchKernelGGL(grid_scan_offsets_kernel, dim3((unsigned)a.N, which), dim3(kScanBlock), 0, a.stream, ws, chunks);
   hipLaunchKernelGGL(grid_scan_apply_kernel, dim3((unsigned)chunks, (unsigned)a.N, which), dim3(kScanBlock), 0,
-                     a.stream, ws, chunks);
+                     a.stream, ws, chunks, refine);
   if (same) PO_BIN(true, false);
   else PO_BIN(true, true);
 #undef PO_BIN
@@ -604,9 +628,9 @@ int grid_build(const KnnArgs& a, const GridWs& ws, const GridBuild& b) {
                      a.P2, a.D, b.c_target, b.h_min, b.ball_radius, b.ball_K, b.ball_factor, b.same ? 1 : 0, ws);
   hipLaunchKernelGGL(grid_prefix_kernel, dim3(1), dim3(64), 0, a.stream, ws, (int)a.N);
   switch (a.D) {
-    case 1: build_d<1>(a, ws, b.same); break;
-    case 2: build_d<2>(a, ws, b.same); break;
-    default: build_d<3>(a, ws, b.same); break;
+    case 1: build_d<1>(a, ws, b.same, b.refine); break;
+    case 2: build_d<2>(a, ws, b.same, b.refine); break;
+    default: build_d<3>(a, ws, b.same, b.refine); break;
   }
   return check_launch("grid build");
 }

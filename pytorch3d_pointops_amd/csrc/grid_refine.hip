@@ -9,10 +9,10 @@
 // re-sorted by sub-cell inside the cell's own range of the sorted array (level-0 searches never notice).  The box
 // search (knn_grid_box.h) walks sub-cell runs of refined cells and whole runs of unrefined ones.
 //
-//   refine_detect  one lane per cell: marks refined cells, hands out descriptors and sub_start tables (atomics);
+//   (detection)    grid_build's scan pass marks the over-full cells and hands out descriptors and sub_start tables;
 //   refine_build   one workgroup per refined cell (persistent over the list): mean / sigma, sub-cell histogram in
 //                  LDS, exclusive scan -> sub_start table, scatter into a scratch copy, copy back.
-// Clouds without over-full cells cost two empty launches.
+// Clouds without over-full cells cost one empty launch.
 #include "grid.h"
 
 namespace pointops {
@@ -20,42 +20,6 @@ namespace pointops {
 constexpr int kRefineBlock = 256;
 constexpr int kRefineWgs = 8;  // workgroups per cloud walking the cloud's list of refined cells (each claims 128 KB
                                // of LDS: 256 of them are one round of the chip, and an empty list costs one round)
-
-__global__ __launch_bounds__(256) void grid_refine_detect_kernel(GridWs ws, int enable) {
-  const int n = blockIdx.y;
-  const GridCloud g = ws.cloud[n];
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ws.cell_cap) return;
-  int ref = -1;
-  if (enable && g.use_grid && c < g.ncell) {
-    const int* __restrict__ cstart = ws.cell_start + (int64_t)n * (ws.cell_cap + 1);
-    const int start = cstart[c], count = cstart[c + 1] - start;
-    if (count > refine_threshold(ws.c_target)) {
-      int s = (int)ceilf(cbrtf((float)count / ws.c_target));
-      s = s < 2 ? 2 : (s > kRefineMaxS ? kRefineMaxS : s);
-      const int cells = s * s * s + 1;
-      const int idx = atomicAdd(ws.rcount + n, 1);
-      if (idx < ws.rdesc_cap) {
-        const int off = atomicAdd(ws.pool_top + n, cells);
-        if (off + cells <= ws.pool_cap) {
-          RefinedCell d;
-          d.start = start;
-          d.count = count;
-          d.s = s;
-          d.pool_off = off;
-          for (int k = 0; k < 3; ++k) d.lo[k] = d.scale[k] = 0.0f;  // filled by refine_build
-          ws.rdesc[(int64_t)n * ws.rdesc_cap + idx] = d;
-          ref = idx;
-        } else {
-          // (the descriptor slot stays unused: count == 0 marks it for refine_build)
-          RefinedCell d{};
-          ws.rdesc[(int64_t)n * ws.rdesc_cap + idx] = d;
-        }
-      }
-    }
-  }
-  ws.refine_ref[(int64_t)n * ws.cell_cap + c] = ref;
-}
 
 template <int D>
 __global__ __launch_bounds__(kRefineBlock) void grid_refine_build_kernel(GridWs ws, int P2) {
@@ -169,10 +133,7 @@ __global__ __launch_bounds__(kRefineBlock) void grid_refine_build_kernel(GridWs 
   }
 }
 
-int grid_refine(const KnnArgs& a, const GridWs& ws, bool enable) {
-  hipLaunchKernelGGL(grid_refine_detect_kernel, dim3((unsigned)ceil_div(ws.cell_cap, 256), (unsigned)a.N), dim3(256), 0,
-                     a.stream, ws, enable ? 1 : 0);
-  if (!enable) return check_launch("grid refine");
+int grid_refine(const KnnArgs& a, const GridWs& ws) {
   const size_t lds = sizeof(int) * (size_t)kRefineMaxS * kRefineMaxS * kRefineMaxS;  // 128 KB: one workgroup per CU
   const dim3 grid(kRefineWgs, (unsigned)a.N);
 #define PO_REFINE(DD)                                                                                            \

@@ -69,9 +69,10 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
   b.c_target = c;
   // the queries are the points (self-KNN): their cell sort is the query order
   b.same = a.p1 == a.p2 && a.l1 == a.l2 && a.P1 == a.P2 && debug_knob("grid_same", 1) != 0;
+  b.refine = debug_knob("grid_refine", 1) != 0 ? 1 : 0;
   int rc = grid_build(a, ws, b);
   if (rc != POINTOPS_OK) return rc;
-  if ((rc = grid_refine(a, ws, debug_knob("grid_refine", 1) != 0)) != POINTOPS_OK) return rc;
+  if (b.refine && (rc = grid_refine(a, ws)) != POINTOPS_OK) return rc;
   const int kc = grid_kc(a.K);
   const bool quad = kc <= 32 && grid_quad_mode(a.P1);  // (64-slot lists: four of them do not fit a quad's registers)
   switch (a.D) {

@@ -1110,3 +1110,34 @@ def test_knn_grid_long_lists(dev, oracle, K, norm):
     assert np.array_equal(bits(r.dists.cpu().numpy()), bits(od))
     r0 = knn_points(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm=norm, K=K, version=0)
     assert torch.equal(r0.idx, r.idx) and torch.equal(r0.dists, r.dists)
+
+
+@pytest.mark.parametrize("K,norm", [(1, 2), (8, 2), (16, 1), (40, 2)])
+def test_knn_refined_cells_and_box_search(dev, oracle, monkeypatch, K, norm):
+    """Clouds whose density varies by orders of magnitude (half of the points in a 1e-3 cube; u^5 per coordinate):
+    over-full cells are refined into sub-grids and the queries of over-full neighbourhoods go through the box
+    search (grid_refine.hip, knn_grid_box.h).  The diagnostics confirm that path ran; results equal the oracle,
+    the run without refinement (boxes over whole cells) and the brute-force family, bit for bit."""
+    from pytorch3d_pointops_amd import _C
+
+    m = 24000
+    a = cases.cloud(2601, (3, 5000, 3))
+    b = cases.cloud(2602, (3, m, 3))
+    a[0, :2500] = a[0, :2500] * np.float32(1e-3) + np.float32(0.5)
+    b[0, : m // 2] = b[0, : m // 2] * np.float32(1e-3) + np.float32(0.5)
+    a[1], b[1] = (a[1] ** np.float32(5.0)).astype(np.float32), (b[1] ** np.float32(5.0)).astype(np.float32)
+    b[2, : m // 3] = b[2, 0]  # a third of the cloud is ONE point: every sub-cell index ties
+    l1, l2 = np.array([5000, 5000, 1234]), np.array([m, m, m - 5])
+    args = (G(a, dev), G(b, dev), G(l1, dev), G(l2, dev), norm, K)
+    idx, d, st = _C.knn_grid_stats(*args)
+    st = st.cpu().numpy()
+    assert (st[:2, 8] > 0).all() and (st[:2, 9] > 0).all(), st  # deferred to the box search, refined cells
+    oi, od = oracle.knn_points_idx(a, b, l1, l2, norm, K)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(bits(d.cpu().numpy()), bits(od))
+    monkeypatch.setenv("POINTOPS_DEBUG", "grid_refine=0")
+    idx0, d0, st0 = _C.knn_grid_stats(*args)
+    assert int(st0[:, 9].sum()) == 0 and torch.equal(idx0, idx) and torch.equal(d0, d)
+    monkeypatch.delenv("POINTOPS_DEBUG")
+    i2, d2 = _C.knn_points_idx(*args, 2 if K <= 32 else 0)
+    assert torch.equal(i2, idx) and torch.equal(d2, d)
