@@ -278,7 +278,8 @@ __global__ void grid_prefix_kernel(GridWs ws, int N) {  // one wave
 // its rank inside the (tile, bin) group) and then touches each non-empty global
 // counter ONCE: count pass  global[bin] += n_tile ;  scatter pass  base = start[bin] +
 // atomicAdd(cursor[bin], n_tile), position = base + rank.  Clouds with more bins than
-// the LDS table holds (kBinLdsBins) use one global atomic per point.
+// the LDS table holds (kBinLdsBins) spend one device atomic per point, or -- tiles with crowded cells -- hash the
+// tile's bins into the same LDS (count pass), and keep every point's final rank for the scatter pass.
 // PAD_ROWS: this launch also writes the rows that get no search (zeros / -1 for padded queries) and lists
 // the queries of clouds without a usable grid for the whole-cloud scan; it is the query count pass, or the
 // point count pass when the queries are the points.
@@ -286,6 +287,9 @@ __global__ void grid_prefix_kernel(GridWs ws, int N) {  // one wave
 constexpr int kBinBlock = 1024;
 constexpr int kBinPerThread = 8;  // tile of 8192 points: 4096 / 8192 / 16384 / 32768 measured 0.988 / 0.969 / 0.987 / 1.125 ms per cfg2 step (chamfer cfg4: 1.14 / 1.13 / 1.22 / 1.66 ms)
 constexpr int kBinTile = kBinBlock * kBinPerThread;
+constexpr int kBinHashBits = 14, kBinHashSlots = 1 << kBinHashBits;  // hash table of the many-bin count pass
+constexpr int kBinCrowdedPairs = 8;
+static_assert(2 * kBinHashSlots <= kBinLdsBins && kBinHashSlots >= 2 * kBinTile, "hash table lives in s_hist");
 
 // One launch bins BOTH sets: blockIdx.z = 0 the points of p2, 1 the queries of p1 (QUERIES = false: points only,
 // the self-query case).
@@ -357,13 +361,78 @@ __global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __rest
       }
       if (use_lds) {
         rank[r] = atomicAdd(&s_hist[bin[r]], 1);  // LDS atomic: rank inside (tile, bin)
-      } else if (!SCATTER) {
-        // too many bins for the LDS table: one device atomic per point, whose return value is the
-        // point's rank in its bin -- remembered, so that the scatter pass needs no second atomic
-        grank[i] = atomicAdd(gcount + bin[r], 1);
-      } else {
+      } else if (SCATTER) {
         rank[r] = gstart[bin[r]] + grank[i];  // final position
       }
+    }
+  }
+  if (!use_lds && !SCATTER) {
+    // Too many bins for a direct LDS table.  A tile of a cloud without crowded cells spends one device atomic per
+    // point (nearly every point of the tile has its own bin; the pass runs at the chip's atomic rate).  A CROWDED
+    // tile -- a cluster that puts half a cloud into one cell serialises tens of thousands of atomics on one address:
+    // 1.6 ms of the K=1 count pass on 8 x 150 000 points -- goes through an LDS HASH table instead (bin -> count,
+    // open addressing; <= 8192 distinct bins in 16384 slots) that hands out the rank inside (tile, bin), and spends
+    // one device atomic per distinct (tile, bin).  Crowded = at least kBinCrowdedPairs of 36 736 sampled pairs of
+    // the tile's points share a bin (pairs at index distances 1 and 1024 k: periodic interleavings of a cluster with
+    // the rest of the cloud do not hide from all of them); a cell with a share f of the points gives 36 736 f^2 of
+    // them, a uniform cloud of 2e5 cells 0.2.
+    __shared__ int s_pairs;
+    if (tid == 0) s_pairs = 0;
+    __syncthreads();
+    int pairs = 0;  // pairs of equal bins among this lane's 8 points (index distances 1024 k) and towards lane + 1
+#pragma unroll
+    for (int r = 0; r < kBinPerThread; ++r) {
+      const int nb = __shfl_down(bin[r], 1, kWave);
+      pairs += (bin[r] >= 0 && nb == bin[r] && (tid & (kWave - 1)) != kWave - 1) ? 1 : 0;
+#pragma unroll
+      for (int q = r + 1; q < kBinPerThread; ++q) pairs += (bin[r] >= 0 && bin[q] == bin[r]) ? 1 : 0;
+    }
+    if (pairs > 0) atomicAdd(&s_pairs, pairs);
+    __syncthreads();
+    const bool crowded = s_pairs >= kBinCrowdedPairs;  // (workgroup-uniform)
+    if (!crowded) {
+      // the point's rank in its bin, remembered so that the scatter pass needs no atomic at all
+#pragma unroll
+      for (int r = 0; r < kBinPerThread; ++r)
+        if (bin[r] >= 0) rank[r] = atomicAdd(gcount + bin[r], 1);
+#pragma unroll
+      for (int r = 0; r < kBinPerThread; ++r)
+        if (bin[r] >= 0) grank[i0 + r * kBinBlock] = rank[r];
+    } else {
+      for (int b = tid; b < kBinHashSlots; b += kBinBlock) {
+        s_hist[b] = -1;                 // keys
+        s_hist[kBinHashSlots + b] = 0;  // counts, then group bases
+      }
+      __syncthreads();
+      int slot[kBinPerThread];
+#pragma unroll
+      for (int r = 0; r < kBinPerThread; ++r) {
+        if (bin[r] < 0) continue;
+        int h = (int)(((unsigned)bin[r] * 2654435761u) >> (32 - kBinHashBits));
+        for (;;) {
+          const int old = atomicCAS(&s_hist[h], -1, bin[r]);
+          if (old == -1 || old == bin[r]) break;
+          h = (h + 1) & (kBinHashSlots - 1);
+        }
+        slot[r] = h;
+        rank[r] = atomicAdd(&s_hist[kBinHashSlots + h], 1);
+      }
+      __syncthreads();
+      // (two loops: all of a thread's device atomics are in flight together; one loop waited for each return)
+      constexpr int kSlotsPerThread = kBinHashSlots / kBinBlock;
+      int base[kSlotsPerThread];
+#pragma unroll
+      for (int s = 0; s < kSlotsPerThread; ++s) {
+        const int h = tid + s * kBinBlock;
+        const int key = s_hist[h];
+        base[s] = key >= 0 ? atomicAdd(gcount + key, s_hist[kBinHashSlots + h]) : 0;  // base of the group
+      }
+#pragma unroll
+      for (int s = 0; s < kSlotsPerThread; ++s) s_hist[kBinHashSlots + tid + s * kBinBlock] = base[s];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < kBinPerThread; ++r)
+        if (bin[r] >= 0) grank[i0 + r * kBinBlock] = s_hist[kBinHashSlots + slot[r]] + rank[r];
     }
   }
   if (use_lds) {
