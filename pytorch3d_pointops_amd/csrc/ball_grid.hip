@@ -19,7 +19,7 @@ template <int D, int KC>
 __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
     const float* __restrict__ p1, const float* __restrict__ p2, const GridCloud* __restrict__ clouds,
     const int* __restrict__ chunk_prefix, const float* __restrict__ edges, const int* __restrict__ cell_start,
-    const float4* __restrict__ sorted, const int* __restrict__ qlist, int* __restrict__ fb_count,
+    const float4* __restrict__ sorted, const float4* __restrict__ qsorted, int* __restrict__ fb_count,
     int* __restrict__ fb_list, int cell_cap, int P1, int P2, int K, int N, float radius2,
     int64_t* __restrict__ idxs, float* __restrict__ dists) {
   constexpr int kQueueCap = KC < 16 ? KC : 16;
@@ -47,17 +47,12 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
     const float4* __restrict__ sp = sorted + (int64_t)n * (P2 + kSortedPad);
     int qi = 0;
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-    if (g.same) {
-      if (active) {
-        const float4 q = sp[c0 + lane];
-        qx = q.x;
-        qy = q.y;
-        qz = q.z;
-        qi = __float_as_int(q.w);
-      }
-    } else if (active) {
-      qi = qlist[(int64_t)n * P1 + c0 + lane];
-      load_point3<D>(p1 + ((int64_t)n * P1 + qi) * D, qx, qy, qz);
+    if (active) {  // query records in cell order (the point records themselves when the queries are the points)
+      const float4 q = (g.same ? sp : qsorted + (int64_t)n * P1)[c0 + lane];
+      qx = q.x;
+      qy = q.y;
+      qz = q.z;
+      qi = __float_as_int(q.w);
     }
     int cx, cy, cz;
     point_cells(g, qx, qy, qz, cx, cy, cz);
@@ -204,7 +199,6 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
 // similar hit patterns -- in the same wave.  The scan kernel then takes these clouds in its list mode
 // (qlist = all queries, coarse-cell order); results do not depend on the order.
 // ---------------------------------------------------------------------------
-constexpr int kOrderG = 16, kOrderBins = kOrderG * kOrderG * kOrderG;
 constexpr int kOrderBlock = 256, kOrderPerThread = 8;
 
 template <int D>
@@ -221,8 +215,8 @@ __device__ __forceinline__ int order_bin(const float* __restrict__ q, const unsi
   return bin;
 }
 
-// SCATTER = false: histogram into qcell_count; true: exclusive scan of the 512 counters (every block, in LDS)
-// + scatter through the cursors in qcell_start
+// SCATTER = false: histogram into order_count; true: exclusive scan of the counters (every block, in LDS)
+// + scatter through the cursors in order_cursor
 template <int D, bool SCATTER>
 __global__ __launch_bounds__(kOrderBlock) void ball_order_kernel(const float* __restrict__ p1, int P1, GridWs ws) {
   const int n = blockIdx.y;
@@ -232,8 +226,8 @@ __global__ __launch_bounds__(kOrderBlock) void ball_order_kernel(const float* __
   const int tid = threadIdx.x;
   const int i0 = blockIdx.x * (kOrderBlock * kOrderPerThread);
   if (i0 >= g.len1) return;
-  int* __restrict__ count = ws.qcell_count + (int64_t)n * ws.cell_cap;
-  int* __restrict__ cursor = ws.qcell_start + (int64_t)n * (ws.cell_cap + 1);
+  int* __restrict__ count = ws.order_count + (int64_t)n * kOrderBins;
+  int* __restrict__ cursor = ws.order_cursor + (int64_t)n * kOrderBins;
   for (int b = tid; b < kOrderBins; b += kOrderBlock) s_bin[b] = SCATTER ? count[b] : 0;
   __syncthreads();
   if (SCATTER) {  // exclusive scan of the counters: kPer per lane + wave scan + 4 wave totals
@@ -287,8 +281,7 @@ __global__ __launch_bounds__(kOrderBlock) void ball_order_kernel(const float* __
   }
 }
 
-// PHASE 0: zero the counters and cursors of the scan-mode clouds (their slices of the query histogram
-// arrays are otherwise unused); PHASE 1, behind the scatter: mark those clouds as "listed"
+// PHASE 0: zero the counters and cursors of the scan-mode clouds; PHASE 1, behind the scatter: mark those clouds as "listed"
 template <int PHASE>
 __global__ void ball_order_aux_kernel(GridWs ws, int N) {
   const int n = blockIdx.x;
@@ -296,8 +289,8 @@ __global__ void ball_order_aux_kernel(GridWs ws, int N) {
   if (g.use_grid || g.len2 <= 0) return;
   if (PHASE == 0) {
     for (int b = threadIdx.x; b < kOrderBins; b += blockDim.x) {
-      ws.qcell_count[(int64_t)n * ws.cell_cap + b] = 0;
-      ws.qcell_start[(int64_t)n * (ws.cell_cap + 1) + b] = 0;
+      ws.order_count[(int64_t)n * kOrderBins + b] = 0;
+      ws.order_cursor[(int64_t)n * kOrderBins + b] = 0;
     }
   } else if (threadIdx.x == 0) {
     ws.grid_flag[n] = 1;
@@ -315,7 +308,7 @@ static void ball_run_d(const KnnArgs& a, float radius2, const GridWs& ws, int wg
 #define PO_BALL(KC)                                                                                              \
   hipLaunchKernelGGL((ball_grid_lane_kernel<D, KC>), dim3((unsigned)wgs), dim3(kGridWave), 0, a.stream, a.p1, a.p2, \
                      (const GridCloud*)ws.cloud, (const int*)ws.chunk_prefix, (const float*)ws.edges,            \
-                     (const int*)ws.cell_start, (const float4*)ws.sorted, (const int*)ws.qlist, ws.fb2_count,    \
+                     (const int*)ws.cell_start, (const float4*)ws.sorted, (const float4*)ws.qsorted, ws.fb2_count,    \
                      ws.fb2_list, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, radius2, a.idxs, a.dists)
   if (a.K <= 8) PO_BALL(8);
   else if (a.K <= 16) PO_BALL(16);
@@ -351,9 +344,8 @@ int ball_grid_run(const KnnArgs& a, float radius, void* workspace, const int** f
     case 2: ball_run_d<2>(a, radius2, ws, wgs); break;
     default: ball_run_d<3>(a, radius2, ws, wgs); break;
   }
-  // scan-mode clouds: all queries, ordered by coarse cell (the histogram arrays of those clouds are unused:
-  // qcell_count was zeroed with the others, qcell_start serves as the scatter cursors)
-  if (debug_knob("ball_order", 1) != 0 && ws.cell_cap >= kOrderBins) {
+  // scan-mode clouds: all queries, ordered by coarse cell
+  if (debug_knob("ball_order", 1) != 0) {
     const dim3 og((unsigned)ceil_div(a.P1, kOrderBlock * kOrderPerThread), (unsigned)a.N);
     hipLaunchKernelGGL(ball_order_aux_kernel<0>, dim3((unsigned)a.N), dim3(256), 0, a.stream, ws, (int)a.N);
 #define PO_ORDER(DD)                                                                                         \

@@ -13,6 +13,10 @@ constexpr int kGMax = 1024;          // cells per dimension cap (edge table size
 constexpr int kEdgeStride = kGMax + 2;
 constexpr int kGridWave = 64;
 constexpr int kNumXcd = 8;           // MI355X: 8 XCDs x 32 CUs, private 4 MB L2 each
+constexpr int kCoarseMax = 2048;     // coarse bins per cloud and set of the two-level sort
+constexpr int kCrowdedMax = 64;      // crowded coarse bins listed per cloud and set (further ones: one workgroup each)
+constexpr int kFineLogMax = 12;      // cells per coarse bin <= 4096
+constexpr int kOrderG = 16, kOrderBins = kOrderG * kOrderG * kOrderG;  // ball query: coarse cells of the scan-mode query order
 constexpr int kSortedPad = 8;        // records of padding behind every cloud's sorted array: record P2 is a NaN
                                      // sentinel (never a candidate); group loads of the lane searches may run
                                      // up to 7 records past a run's end and stay inside the cloud's array
@@ -25,6 +29,7 @@ struct GridCloud {
   int len1, len2;
   int use_grid;
   int same;  // 1 = the queries ARE the points (p1 == p2, lengths1 == lengths2): the point sort is the query order
+  int shift[2], nbin[2];  // two-level sort (grid_build.hip): coarse bin = cell id >> shift, per set (0 points, 1 queries)
 };
 
 // A REFINED cell: a level-0 cell holding far more points than the target gets its own s x s x s sub-grid over the
@@ -41,12 +46,21 @@ struct GridWs {
   GridCloud* cloud;   // N
   int* chunk_prefix;  // N + 1     64-query chunks of the clouds before cloud n
   float* edges;       // N * 3 * kEdgeStride
-  int* cell_count;    // N * cell_cap   histogram, then scatter cursor
   int* cell_start;    // N * (cell_cap + 1)
+  int* coarse_count;  // N * 2 * (kCoarseMax + 1)   entries per coarse bin (set 0 points, 1 queries)
+  int* coarse_cursor; // N * 2 * (kCoarseMax + 1)   groups handed out so far
+  int* coarse_start;  // N * 2 * (kCoarseMax + 1)   exclusive scan of coarse_count
   float4* sorted;     // N * (P2 + kSortedPad)   (x, y, z, idx bits) by cell
-  int* qcell_count;   // N * cell_cap   queries per cell
-  int* qcell_start;   // N * (cell_cap + 1)
-  int* qlist;         // N * P1         query ids grouped by cell
+  int* coarse_ticket; // N * 2           tiles of the count launch that have finished
+  int* crowded_count; // N * 2           crowded coarse bins (<= kCrowdedMax), listed in
+  int* crowded_list;  // N * 2 * kCrowdedMax
+  int* fine_count;    // N * 2 * cell_cap   records per cell, maintained for the cells of crowded bins only
+  int* prank;         // N * P2          rank of a record inside its cell (records of crowded bins only)
+  int* qrank;         // N * P1
+  float4* qtmp;       // N * P1         query records grouped by coarse bin
+  float4* qsorted;    // N * P1         query records (x, y, z, idx bits) by cell: the query order of the lane searches
+  int* order_count;   // N * kOrderBins ball query: coarse query order of the scan-mode clouds (ball_grid.hip)
+  int* order_cursor;  // N * kOrderBins
   int* fb_count;      // N          queries the lane search could not certify
   int* fb_list;       // N * P1
   unsigned* fb_kth;   // N * P1     estimated KC-th distance (fp32 bits) of an uncertified query: picks the quad pass's cube
@@ -55,9 +69,6 @@ struct GridWs {
   int* fb3_count;     // N          queries the radius-2 quad search could not certify (expanding search)
   int* fb3_list;      // N * P1
   unsigned* bbox;     // N * 8: ordered-uint keys of min x,y,z (atomicMin) and max x,y,z (atomicMax)
-  int* scan_partial;  // N * 2 * ceil(cell_cap / 4096): per-chunk sums / offsets of the two scans
-  int* rank1;         // N * P1     rank of a query / point inside its bin (many-bin clouds only)
-  int* rank2;         // N * P2
   int* grid_flag;     // N          1 = the cloud was searched through its grid (ball query: scan only the list)
   // refined cells and the box search (grid_refine.hip, knn_grid_box.h)
   int* refine_ref;    // N * cell_cap   per cell: index of its RefinedCell, or -1
@@ -65,7 +76,7 @@ struct GridWs {
   int* rcount;        // N          refined cells of the cloud (may exceed rdesc_cap: clamp)
   int* pool;          // N * pool_cap   sub_start tables
   int* pool_top;      // N
-  float4* sorted_tmp; // N * P2     scratch of the in-cell re-sort
+  float4* sorted_tmp; // N * P2     records grouped by coarse bin; later the scratch of the in-cell re-sort
   int* box_count;     // N          queries deferred to the box search
   int* box_list;      // N * P1
   int rdesc_cap, pool_cap;

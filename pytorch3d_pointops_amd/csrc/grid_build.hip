@@ -5,10 +5,13 @@
 //                    and per-dimension EDGE TABLES E_d[c] = min{ x in [lo,hi] : cell_d(x) >= c }, found by
 //                    bisection over the ordered fp32 bit patterns of the (monotone) cell function itself --
 //                    no error analysis of the binning arithmetic is needed;
-//   2 grid_bin<cnt>  histograms: p2 points per cell, p1 queries per cell (LDS-aggregated, one global
-//                    atomic per non-empty bin and tile); zero rows for padded queries;
-//   3 grid_scan_*    chunked exclusive scans -> cell_start / qcell_start;
-//   4 grid_bin<sct>  counting-sort p2 into (x,y,z,idx) float4 records, query ids into per-cell lists.
+//   2 grid_partition<count>   entries per COARSE bin (a contiguous range of ~1000-2000 entries' worth of cells): p2 points
+//                    and p1 queries, LDS histogram per tile, one device atomic per (tile, bin); zero rows for padded
+//                    queries;
+//   3 grid_partition<scatter> (x,y,z,idx) float4 records of points and of queries, grouped by coarse bin;
+//   4 grid_sort      one workgroup per coarse bin: cells counted, scanned and sorted in LDS -> cell_start, the
+//                    point records by cell, the query records by cell (the searches read their queries
+//                    coalesced, in cell order), the refined-cell marks.
 // When the queries ARE the points (same buffer, same lengths: self-KNN, ball query of a cloud on itself,
 // get_point_covariances) the query passes are skipped: the point sort is the query order.
 #include <stdlib.h>
@@ -18,8 +21,9 @@
 namespace pointops {
 
 constexpr int kSetupBlock = 1024;  // 3 x 1026 edge bisections per cloud
-constexpr int kScanBlock = 1024;
-constexpr int kBinLdsBins = 40000;  // 156 KiB of LDS: the whole CU's LDS, one workgroup per CU
+constexpr int kCoarsePoints = 1024;  // entries a coarse bin of the two-level sort aims at
+
+__device__ __forceinline__ int64_t coarse_row(int n, int set) { return ((int64_t)n * 2 + set) * (kCoarseMax + 1); }
 
 // smallest x in [lo, hi] with cell_of(x) >= c, +inf if none
 __device__ float edge_bisect(int c, float lo, float hi, float inv_h, int G) {
@@ -199,13 +203,8 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
           }
           cells *= G[d];
         }
-        // A histogram that fits the binning pass's LDS table is ~3x cheaper to build than one that
-        // needs a global atomic per point: when the cell count is within 2x of the table, grow h a
-        // little (cells ~ h^-3) until it fits.
-        if (cells <= (long long)ws.cell_cap &&
-            !(cells > (long long)kBinLdsBins && cells <= 2LL * kBinLdsBins))
-          break;
-        h *= cells > (long long)ws.cell_cap ? 1.2599211f : 1.04f;  // halve the cell count / nudge
+        if (cells <= (long long)ws.cell_cap) break;
+        h *= 1.2599211f;  // halve the cell count
       }
       if ((long long)G[0] * G[1] * G[2] > (long long)ws.cell_cap) ok = false;
     }
@@ -218,6 +217,17 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     g.ncell = G[0] * G[1] * G[2];
     g.len1 = len1;
     g.len2 = len2;
+    // coarse bins of the two-level sort: cell id >> shift, with ~kCoarsePoints entries per bin and <= kCoarseMax bins
+    for (int set = 0; set < 2; ++set) {
+      const long long len = set ? len1 : len2;
+      int shift = 0;
+      while (shift < kFineLogMax && ((((g.ncell - 1) >> shift) + 1 > kCoarseMax) ||
+                                     (len << shift) < (long long)kCoarsePoints * g.ncell))
+        ++shift;
+      g.shift[set] = shift;
+      g.nbin[set] = ((g.ncell - 1) >> shift) + 1;
+      if (g.nbin[set] > kCoarseMax) ok = false;
+    }
     g.use_grid = ok ? 1 : 0;
     g.same = same;
     s_g = g;
@@ -231,6 +241,14 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     ws.rcount[n] = 0;
     ws.pool_top[n] = 0;
     ws.box_count[n] = 0;
+  }
+  for (int t = tid; t < 2 * (kCoarseMax + 1); t += kSetupBlock) {  // counters and cursors of the partition passes
+    ws.coarse_count[coarse_row(n, 0) + t] = 0;
+    ws.coarse_cursor[coarse_row(n, 0) + t] = 0;
+  }
+  if (tid < 2) {
+    ws.coarse_ticket[n * 2 + tid] = 0;
+    ws.crowded_count[n * 2 + tid] = 0;
   }
   __syncthreads();
   if (s_g.use_grid) {
@@ -269,35 +287,60 @@ __global__ void grid_prefix_kernel(GridWs ws, int N) {  // one wave
 }
 
 // ---------------------------------------------------------------------------
-// pass 2 / 4: histogram and counting-sort scatter (SCATTER = false / true), for the
-// points of p2 by cell (IS_QUERY = false) and the queries of p1 by cell (true).
+// passes 2-4: two-level counting sort of the points of p2 (set 0) and the queries of p1 (set 1) by cell.
 //
-// Scattered device-scope atomics run at only ~2e10/s chip-wide (they execute at the
-// memory side, one 64-byte request each), so a workgroup first bins its tile of
-// 1024 x 8 points in an LDS histogram (fast LDS atomics, which also hand every point
-// its rank inside the (tile, bin) group) and then touches each non-empty global
-// counter ONCE: count pass  global[bin] += n_tile ;  scatter pass  base = start[bin] +
-// atomicAdd(cursor[bin], n_tile), position = base + rank.  Clouds with more bins than
-// the LDS table holds (kBinLdsBins) spend one device atomic per point, or -- tiles with crowded cells -- hash the
-// tile's bins into the same LDS (count pass), and keep every point's final rank for the scatter pass.
-// PAD_ROWS: this launch also writes the rows that get no search (zeros / -1 for padded queries) and lists
-// the queries of clouds without a usable grid for the whole-cloud scan; it is the query count pass, or the
-// point count pass when the queries are the points.
+// The inputs arrive in storage order, so a tile of a few thousand points touches about as many distinct cells:
+// a direct counting sort costs one scattered device-scope atomic per point (they execute at the memory side,
+// ~2e10/s chip-wide: 105 us for the 2.4 M points and queries of the K=1 / chamfer case) and a 16-byte store at a
+// random position of a megabyte-sized array (4x write amplification).  Instead:
+//   PARTITION  (count, then scatter; tiles of 8192 entries) by COARSE bin = cell id >> shift, a contiguous range of
+//              2^shift cells with ~1000-2000 entries (<= 2048 bins per cloud: an LDS histogram per tile, ONE device atomic
+//              per non-empty (tile, bin), runs of tens to hundreds of records written together);
+//   SORT       one workgroup per coarse bin: histogram of the bin's cells in LDS, exclusive scan -> the bin's slice
+//              of cell_start (and the refined-cell bookkeeping), then the records move to their final place inside the
+//              bin's own compact range of the sorted array (second read from L2).
+// No per-cell global counters, no global scans, no memset.  A crowded bin (a cluster) is simply a long loop of one
+// workgroup.  PAD_ROWS: the count launch also writes the rows that get no search (zeros / -1 for padded queries) and
+// lists the queries of clouds without a usable grid for the whole-cloud scan.
 // ---------------------------------------------------------------------------
-constexpr int kBinBlock = 1024;
-constexpr int kBinPerThread = 8;  // tile of 8192 points: 4096 / 8192 / 16384 / 32768 measured 0.988 / 0.969 / 0.987 / 1.125 ms per cfg2 step (chamfer cfg4: 1.14 / 1.13 / 1.22 / 1.66 ms)
-constexpr int kBinTile = kBinBlock * kBinPerThread;
-constexpr int kBinHashBits = 14, kBinHashSlots = 1 << kBinHashBits;  // hash table of the many-bin count pass
-constexpr int kBinCrowdedPairs = 8;
-static_assert(2 * kBinHashSlots <= kBinLdsBins && kBinHashSlots >= 2 * kBinTile, "hash table lives in s_hist");
+constexpr int kPartBlock = 1024;
+constexpr int kPartPerThread = 8;  // tile of 8192 entries
+constexpr int kPartTile = kPartBlock * kPartPerThread;
+constexpr int kSortBlock = 256;  // (512 / 1024 threads: 89 / 157 us instead of 62 us for the cfg2 sort pass)
+constexpr int kHashBits = 12, kHashSlots = 1 << kHashBits, kHashProbes = 8;  // partition pass: cells of crowded bins
+constexpr int kCrowded = 8192;       // records from which a coarse bin is CROWDED: sorted by slices (grid_sort_kernel)
+constexpr int kCrowdedSlice = 4096;  // records per slice
+constexpr int kFineMax = 1 << kFineLogMax;  // cells per coarse bin cap: the LDS counters of one sort workgroup
+static_assert(kCoarseMax == 2 * kPartBlock, "the partition pass scans two coarse counters per thread");
 
-// One launch bins BOTH sets: blockIdx.z = 0 the points of p2, 1 the queries of p1 (QUERIES = false: points only,
+// atomicAdd(&counter[slot], 1) of every live lane of a wave; when all of them name the SAME counter (a bin whose
+// records sit in one cell: 64 LDS atomics on one address serialise) they spend one atomic.  Returns what the lane's
+// own atomicAdd would have (a rank unique per counter).  Call it from wave-uniform control flow only.
+__device__ __forceinline__ int wave_add(int* __restrict__ counter, int slot, bool live) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned long long todo = __ballot(live);
+  if (todo == 0ull) return 0;
+  const int leader = __ffsll((long long)todo) - 1;
+  const int s0 = __shfl(slot, leader, kWave);
+  if ((__ballot(live && slot == s0)) == todo) {  // (wave-uniform)
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counter[s0], __popcll(todo));
+    base = __shfl(base, leader, kWave);
+    return base + __popcll(todo & ((1ull << lane) - 1ull));
+  }
+  return live ? atomicAdd(&counter[slot], 1) : 0;
+}
+
+// One launch handles BOTH sets: blockIdx.z = 0 the points of p2, 1 the queries of p1 (QUERIES = false: points only,
 // the self-query case).
 template <int D, bool SCATTER, bool QUERIES>
-__global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __restrict__ p2, int P2,
-                                                           const float* __restrict__ p1, int P1, int K, GridWs ws,
-                                                           int64_t* __restrict__ idxs, float* __restrict__ dists) {
-  __shared__ int s_hist[kBinLdsBins];
+__global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float* __restrict__ p2, int P2,
+                                                                 const float* __restrict__ p1, int P1, int K,
+                                                                 GridWs ws, int64_t* __restrict__ idxs,
+                                                                 float* __restrict__ dists) {
+  __shared__ int s_hist[kCoarseMax];   // entries of this tile per coarse bin; then the base of the tile's group
+  __shared__ int s_start[kCoarseMax];  // SCATTER: exclusive scan of the cloud's coarse counts
+  __shared__ int s_wsum[kPartBlock / kWave];
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
   const bool IS_QUERY = QUERIES && blockIdx.z == 1;   // (workgroup-uniform)
@@ -305,21 +348,21 @@ __global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __rest
   const float* __restrict__ pts = IS_QUERY ? p1 : p2;
   const int P = IS_QUERY ? P1 : P2;
   const GridCloud g = ws.cloud[n];  // wave-uniform
+  const int set = IS_QUERY ? 1 : 0;
   const int len = IS_QUERY ? g.len1 : g.len2;
-  const int nbins = g.ncell;
-  const int64_t cbase = (int64_t)n * ws.cell_cap;
-  int* __restrict__ gcount = (IS_QUERY ? ws.qcell_count : ws.cell_count) + cbase;
-  const int* __restrict__ gstart = (IS_QUERY ? ws.qcell_start : ws.cell_start) + (int64_t)n * (ws.cell_cap + 1);
-  int* __restrict__ grank = (IS_QUERY ? ws.rank1 : ws.rank2) + (int64_t)n * P;
-  const int i0 = blockIdx.x * kBinTile + tid;
-  if (blockIdx.x * kBinTile >= P) return;
+  const int shift = g.shift[set], nbin = g.nbin[set];
+  int* __restrict__ gcount = ws.coarse_count + coarse_row(n, set);
+  int* __restrict__ gcursor = ws.coarse_cursor + coarse_row(n, set);
+  int* __restrict__ gstart = ws.coarse_start + coarse_row(n, set);
+  const int i0 = blockIdx.x * kPartTile + tid;
+  if (blockIdx.x * kPartTile >= P) return;
 
   if (PAD_ROWS && !SCATTER) {
     // rows that get no search: zeros for padded queries (knn_cpu.cpp:25-26); whole-cloud list
     // when this cloud has no usable grid
 #pragma unroll 4
-    for (int r = 0; r < kBinPerThread; ++r) {
-      const int i = i0 + r * kBinBlock;
+    for (int r = 0; r < kPartPerThread; ++r) {
+      const int i = i0 + r * kPartBlock;
       if (i < P && i >= g.len1) {
         int64_t* __restrict__ zi = idxs + ((int64_t)n * P + i) * K;
         float* __restrict__ zd = dists + ((int64_t)n * P + i) * K;
@@ -334,18 +377,38 @@ __global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __rest
       }
     }
   }
-  if (!g.use_grid || blockIdx.x * kBinTile >= len) return;
+  if (!g.use_grid || blockIdx.x * kPartTile >= len) return;
 
-  const bool use_lds = nbins <= kBinLdsBins;
-  if (use_lds) {
-    for (int b = tid; b < nbins; b += kBinBlock) s_hist[b] = 0;
-    __syncthreads();
-  }
-  int bin[kBinPerThread], rank[kBinPerThread];
-  float px[kBinPerThread], py[kBinPerThread], pz[kBinPerThread];
+  for (int b = tid; b < nbin; b += kPartBlock) s_hist[b] = 0;
+  if (SCATTER) {
+    // exclusive scan of the cloud's coarse counts (every tile redoes it: <= 2048 counters from L2)
+    const int v0 = 2 * tid < nbin ? gcount[2 * tid] : 0;
+    const int v1 = 2 * tid + 1 < nbin ? gcount[2 * tid + 1] : 0;
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    int inc = v0 + v1;
 #pragma unroll
-  for (int r = 0; r < kBinPerThread; ++r) {
-    const int i = i0 + r * kBinBlock;
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int u = __shfl_up(inc, off, kWave);
+      if (lane >= off) inc += u;
+    }
+    if (lane == kWave - 1) s_wsum[wave] = inc;
+    __syncthreads();
+    int excl = inc - v0 - v1;
+    for (int w = 0; w < wave; ++w) excl += s_wsum[w];
+    s_start[2 * tid] = excl;
+    s_start[2 * tid + 1] = excl + v0;
+    if (blockIdx.x == 0) {  // the table the sort pass reads: starts of the bins and the total behind them
+      gstart[2 * tid] = excl;
+      gstart[2 * tid + 1] = excl + v0;
+      if (tid == kPartBlock - 1) gstart[kCoarseMax] = excl + v0 + v1;
+    }
+  }
+  __syncthreads();
+  int bin[kPartPerThread], rank[kPartPerThread];
+  float px[kPartPerThread], py[kPartPerThread], pz[kPartPerThread];
+#pragma unroll
+  for (int r = 0; r < kPartPerThread; ++r) {
+    const int i = i0 + r * kPartBlock;
     bin[r] = -1;
     rank[r] = 0;
     if (i < len) {
@@ -354,255 +417,324 @@ __global__ __launch_bounds__(kBinBlock) void grid_bin_kernel(const float* __rest
       int cx, cy, cz;
       point_cells(g, x, y, z, cx, cy, cz);
       bin[r] = (cz * g.G[1] + cy) * g.G[0] + cx;
-      if (SCATTER && !IS_QUERY) {
+      if (SCATTER) {
         px[r] = x;
         py[r] = y;
         pz[r] = z;
       }
-      if (use_lds) {
-        rank[r] = atomicAdd(&s_hist[bin[r]], 1);  // LDS atomic: rank inside (tile, bin)
-      } else if (SCATTER) {
-        rank[r] = gstart[bin[r]] + grank[i];  // final position
+      rank[r] = atomicAdd(&s_hist[bin[r] >> shift], 1);  // LDS atomic: rank inside (tile, coarse bin)
+    }
+  }
+  __syncthreads();
+  for (int b = tid; b < nbin; b += kPartBlock) {
+    const int c = s_hist[b];
+    if (c > 0) {
+      if (!SCATTER) {
+        const int before = atomicAdd(gcount + b, c);
+        asm volatile("" ::"v"(before));  // a RETURNING atomic: performed before this wave passes the barrier below
+      } else {
+        s_hist[b] = s_start[b] + atomicAdd(gcursor + b, c);  // base of this tile's group
       }
     }
   }
-  if (!use_lds && !SCATTER) {
-    // Too many bins for a direct LDS table.  A tile of a cloud without crowded cells spends one device atomic per
-    // point (nearly every point of the tile has its own bin; the pass runs at the chip's atomic rate).  A CROWDED
-    // tile -- a cluster that puts half a cloud into one cell serialises tens of thousands of atomics on one address:
-    // 1.6 ms of the K=1 count pass on 8 x 150 000 points -- goes through an LDS HASH table instead (bin -> count,
-    // open addressing; <= 8192 distinct bins in 16384 slots) that hands out the rank inside (tile, bin), and spends
-    // one device atomic per distinct (tile, bin).  Crowded = at least kBinCrowdedPairs of 36 736 sampled pairs of
-    // the tile's points share a bin (pairs at index distances 1 and 1024 k: periodic interleavings of a cluster with
-    // the rest of the cloud do not hide from all of them); a cell with a share f of the points gives 36 736 f^2 of
-    // them, a uniform cloud of 2e5 cells 0.2.
-    __shared__ int s_pairs;
-    if (tid == 0) s_pairs = 0;
+  int* __restrict__ fine = ws.fine_count + (int64_t)(n * 2 + set) * ws.cell_cap;
+  int* __restrict__ clist = ws.crowded_list + (int64_t)(n * 2 + set) * kCrowdedMax;
+  if (!SCATTER) {
+    // The LAST tile of the (cloud, set) to finish lists the CROWDED bins (see grid_sort_kernel) and zeroes their
+    // per-cell counters for the scatter launch.
+    // (No agent-scope fence: on this chip it writes back the whole L2.  The counters are only ever touched by
+    // device-scope atomics, which execute at the memory side; a tile's atomics have returned before its ticket is
+    // drawn, and the last tile reads the counters with device-scope atomic loads.)
+    __shared__ int s_last, s_ncrowd;
     __syncthreads();
-    int pairs = 0;  // pairs of equal bins among this lane's 8 points (index distances 1024 k) and towards lane + 1
-#pragma unroll
-    for (int r = 0; r < kBinPerThread; ++r) {
-      const int nb = __shfl_down(bin[r], 1, kWave);
-      pairs += (bin[r] >= 0 && nb == bin[r] && (tid & (kWave - 1)) != kWave - 1) ? 1 : 0;
-#pragma unroll
-      for (int q = r + 1; q < kBinPerThread; ++q) pairs += (bin[r] >= 0 && bin[q] == bin[r]) ? 1 : 0;
+    if (tid == 0) {
+      const int tiles = (len + kPartTile - 1) / kPartTile;
+      s_last = atomicAdd(ws.coarse_ticket + n * 2 + set, 1) == tiles - 1;
+      s_ncrowd = 0;
     }
-    if (pairs > 0) atomicAdd(&s_pairs, pairs);
     __syncthreads();
-    const bool crowded = s_pairs >= kBinCrowdedPairs;  // (workgroup-uniform)
-    if (!crowded) {
-      // the point's rank in its bin, remembered so that the scatter pass needs no atomic at all
-#pragma unroll
-      for (int r = 0; r < kBinPerThread; ++r)
-        if (bin[r] >= 0) rank[r] = atomicAdd(gcount + bin[r], 1);
-#pragma unroll
-      for (int r = 0; r < kBinPerThread; ++r)
-        if (bin[r] >= 0) grank[i0 + r * kBinBlock] = rank[r];
-    } else {
-      for (int b = tid; b < kBinHashSlots; b += kBinBlock) {
-        s_hist[b] = -1;                 // keys
-        s_hist[kBinHashSlots + b] = 0;  // counts, then group bases
-      }
-      __syncthreads();
-      int slot[kBinPerThread];
-#pragma unroll
-      for (int r = 0; r < kBinPerThread; ++r) {
-        if (bin[r] < 0) continue;
-        int h = (int)(((unsigned)bin[r] * 2654435761u) >> (32 - kBinHashBits));
-        for (;;) {
-          const int old = atomicCAS(&s_hist[h], -1, bin[r]);
-          if (old == -1 || old == bin[r]) break;
-          h = (h + 1) & (kBinHashSlots - 1);
-        }
-        slot[r] = h;
-        rank[r] = atomicAdd(&s_hist[kBinHashSlots + h], 1);
-      }
-      __syncthreads();
-      // (two loops: all of a thread's device atomics are in flight together; one loop waited for each return)
-      constexpr int kSlotsPerThread = kBinHashSlots / kBinBlock;
-      int base[kSlotsPerThread];
-#pragma unroll
-      for (int s = 0; s < kSlotsPerThread; ++s) {
-        const int h = tid + s * kBinBlock;
-        const int key = s_hist[h];
-        base[s] = key >= 0 ? atomicAdd(gcount + key, s_hist[kBinHashSlots + h]) : 0;  // base of the group
-      }
-#pragma unroll
-      for (int s = 0; s < kSlotsPerThread; ++s) s_hist[kBinHashSlots + tid + s * kBinBlock] = base[s];
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < kBinPerThread; ++r)
-        if (bin[r] >= 0) grank[i0 + r * kBinBlock] = s_hist[kBinHashSlots + slot[r]] + rank[r];
-    }
-  }
-  if (use_lds) {
-    __syncthreads();
-    for (int b = tid; b < nbins; b += kBinBlock) {
-      const int c = s_hist[b];
-      if (c > 0) {
-        if (!SCATTER) atomicAdd(gcount + b, c);
-        else s_hist[b] = gstart[b] + atomicAdd(gcount + b, c);  // base of this tile's group
-      }
-    }
-    if (SCATTER) __syncthreads();
-  }
-  if (SCATTER) {
-#pragma unroll
-    for (int r = 0; r < kBinPerThread; ++r) {
-      if (bin[r] >= 0) {
-        const int i = i0 + r * kBinBlock;
-        const int pos = use_lds ? s_hist[bin[r]] + rank[r] : rank[r];
-        if (IS_QUERY) ws.qlist[(int64_t)n * P + pos] = i;
-        else ws.sorted[(int64_t)n * (P + kSortedPad) + pos] = make_float4(px[r], py[r], pz[r], __int_as_float(i));
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// pass 3: exclusive scans of the cell and block histograms, chunked over all CUs:
-//   a) every (chunk, cloud) workgroup sums its 4096 counters -> partial[cloud][chunk]
-//   b) one workgroup per cloud turns the partials into chunk offsets (+ grand total)
-//   c) every (chunk, cloud) workgroup rescans its chunk from its offset, writes the starts
-//      and resets the counters to 0 so they can serve as scatter cursors.
-// (a single workgroup per cloud took 0.43 ms at 2e5 cells -- the K=1 / chamfer regime.)
-// ---------------------------------------------------------------------------
-constexpr int kScanChunk = 4096;  // counters per workgroup: 1024 lanes x int4
-
-__device__ __forceinline__ int block_sum_1024(int v, int* s_red) {
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-  if (lane == 0) s_red[wave] = v;
-  __syncthreads();
-  int t = lane < kScanBlock / kWave ? s_red[lane] : 0;
-#pragma unroll
-  for (int off = kScanBlock / kWave / 2; off > 0; off >>= 1) t += __shfl_xor(t, off, kWave);
-  __syncthreads();
-  return t;  // every lane of every wave holds the block total
-}
-
-// which: 0 = points per cell, 1 = queries per cell
-__device__ __forceinline__ void scan_arrays(const GridWs& ws, int n, int which, int*& count, int*& start,
-                                            int& len) {
-  const GridCloud g = ws.cloud[n];
-  count = (which == 0 ? ws.cell_count : ws.qcell_count) + (int64_t)n * ws.cell_cap;
-  start = (which == 0 ? ws.cell_start : ws.qcell_start) + (int64_t)n * (ws.cell_cap + 1);
-  len = g.use_grid ? g.ncell : 0;
-}
-
-__global__ __launch_bounds__(kScanBlock) void grid_scan_partial_kernel(GridWs ws, int chunks) {
-  __shared__ int s_red[kScanBlock / kWave];
-  const int n = blockIdx.y, which = blockIdx.z, chunk = blockIdx.x;
-  int *count, *start, len;
-  scan_arrays(ws, n, which, count, start, len);
-  if (chunk * kScanChunk >= len) return;
-  int v = 0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = chunk * kScanChunk + threadIdx.x * 4 + r;
-    if (i < len) v += count[i];
-  }
-  const int tot = block_sum_1024(v, s_red);
-  if (threadIdx.x == 0) ws.scan_partial[((int64_t)n * 2 + which) * chunks + chunk] = tot;
-}
-
-__global__ __launch_bounds__(kScanBlock) void grid_scan_offsets_kernel(GridWs ws, int chunks) {
-  // chunks <= 1024 is guaranteed by the host (cell_cap <= 4M)
-  __shared__ int s_red[kScanBlock / kWave];
-  const int n = blockIdx.x, which = blockIdx.y;
-  int *count, *start, len;
-  scan_arrays(ws, n, which, count, start, len);
-  const int used = (len + kScanChunk - 1) / kScanChunk;
-  int* __restrict__ part = ws.scan_partial + ((int64_t)n * 2 + which) * chunks;
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int v = tid < used ? part[tid] : 0;
-  int inc = v;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const int u = __shfl_up(inc, off, kWave);
-    if (lane >= off) inc += u;
-  }
-  if (lane == kWave - 1) s_red[wave] = inc;
-  __syncthreads();
-  if (wave == 0) {
-    const int w = lane < kScanBlock / kWave ? s_red[lane] : 0;
-    int winc = w;
-#pragma unroll
-    for (int off = 1; off < kScanBlock / kWave; off <<= 1) {
-      const int u = __shfl_up(winc, off, kWave);
-      if (lane >= off) winc += u;
-    }
-    if (lane < kScanBlock / kWave) s_red[lane] = winc - w;
-  }
-  __syncthreads();
-  if (tid < used) part[tid] = s_red[wave] + inc - v;  // exclusive chunk offset
-  if (len > 0 && tid == used - 1) start[len] = s_red[wave] + inc;  // grand total
-  if (len == 0 && tid == 0 && ws.cloud[n].use_grid) start[0] = 0;
-}
-
-// `refine` != 0: the pass over the point cells also marks the over-full ones for refinement (grid_refine.hip):
-// a descriptor and a sub_start table from the cloud's pool, the sub-grid itself is built by refine_build.
-__global__ __launch_bounds__(kScanBlock) void grid_scan_apply_kernel(GridWs ws, int chunks, int refine) {
-  __shared__ int s_red[kScanBlock / kWave];
-  const int n = blockIdx.y, which = blockIdx.z, chunk = blockIdx.x;
-  int *count, *start, len;
-  scan_arrays(ws, n, which, count, start, len);
-  if (chunk * kScanChunk >= len) return;
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int i0 = chunk * kScanChunk + tid * 4;
-  int c[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) c[r] = (i0 + r < len) ? count[i0 + r] : 0;
-  const int sum = c[0] + c[1] + c[2] + c[3];
-  int inc = sum;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const int u = __shfl_up(inc, off, kWave);
-    if (lane >= off) inc += u;
-  }
-  if (lane == kWave - 1) s_red[wave] = inc;
-  __syncthreads();
-  if (wave == 0) {
-    const int w = lane < kScanBlock / kWave ? s_red[lane] : 0;
-    int winc = w;
-#pragma unroll
-    for (int off = 1; off < kScanBlock / kWave; off <<= 1) {
-      const int u = __shfl_up(winc, off, kWave);
-      if (lane >= off) winc += u;
-    }
-    if (lane < kScanBlock / kWave) s_red[lane] = winc - w;
-  }
-  __syncthreads();
-  int run = ws.scan_partial[((int64_t)n * 2 + which) * chunks + chunk] + s_red[wave] + inc - sum;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (i0 + r < len) {
-      start[i0 + r] = run;
-      if (which == 0 && refine >= 0) {
-        int ref = -1;
-        if (refine > 0 && c[r] > refine_threshold(ws.c_target)) {
-          int s = (int)ceilf(cbrtf((float)c[r] / ws.c_target));
-          s = s < 2 ? 2 : (s > kRefineMaxS ? kRefineMaxS : s);
-          const int cells = s * s * s + 1;
-          const int idx = atomicAdd(ws.rcount + n, 1);
-          if (idx < ws.rdesc_cap) {
-            RefinedCell d{};  // count == 0: a descriptor without a table (pool exhausted), skipped by refine_build
-            const int off = atomicAdd(ws.pool_top + n, cells);
-            if (off + cells <= ws.pool_cap) {
-              d.start = run;
-              d.count = c[r];
-              d.s = s;
-              d.pool_off = off;
-              ref = idx;
-            }
-            ws.rdesc[(int64_t)n * ws.rdesc_cap + idx] = d;
+    if (s_last) {  // (workgroup-uniform)
+      for (int b = tid; b < nbin; b += kPartBlock) {
+        const int c = __hip_atomic_load(gcount + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c > kCrowded) {
+          const int k = atomicAdd(&s_ncrowd, 1);
+          if (k < kCrowdedMax) {
+            clist[k] = b;
+            s_hist[k] = b;  // (the tile's histogram is no longer needed)
           }
         }
-        ws.refine_ref[(int64_t)n * ws.cell_cap + i0 + r] = ref;
       }
-      run += c[r];
-      count[i0 + r] = 0;
+      __syncthreads();
+      const int nc = min(s_ncrowd, kCrowdedMax);
+      if (tid == 0) ws.crowded_count[n * 2 + set] = nc;
+      for (int k = 0; k < nc; ++k) {
+        const int f0 = s_hist[k] << shift;
+        const int nf = min(1 << shift, g.ncell - f0);
+        for (int f = tid; f < nf; f += kPartBlock) fine[f0 + f] = 0;
+      }
+    }
+  }
+  if (SCATTER) {
+    __shared__ unsigned s_crowd[kCoarseMax / 32];  // bitmap of the crowded bins
+    const int nc = ws.crowded_count[n * 2 + set];  // (workgroup-uniform; 0 unless the cloud is skewed)
+    if (nc > 0) {
+      for (int w = tid; w < kCoarseMax / 32; w += kPartBlock) s_crowd[w] = 0u;
+      __syncthreads();
+      if (tid < nc) {
+        const int b = clist[tid];
+        atomicOr(&s_crowd[b >> 5], 1u << (b & 31));
+      }
+    }
+    __syncthreads();
+    int* __restrict__ grank = (IS_QUERY ? ws.qrank : ws.prank) + (int64_t)n * P;
+    int pos[kPartPerThread];
+#pragma unroll
+    for (int r = 0; r < kPartPerThread; ++r) {
+      pos[r] = -1;
+      if (bin[r] >= 0) {
+        const int i = i0 + r * kPartBlock;
+        pos[r] = s_hist[bin[r] >> shift] + rank[r];
+        (IS_QUERY ? ws.qtmp : ws.sorted_tmp)[(int64_t)n * P + pos[r]] =
+            make_float4(px[r], py[r], pz[r], __int_as_float(i));
+      }
+    }
+    if (nc > 0) {
+      // Records of crowded bins: rank inside the CELL, counted in fine_count.  The tile's records of one cell share
+      // ONE device atomic through an LDS hash table (cell -> count, open addressing, at most kHashProbes probes; a
+      // record that finds no slot spends its own atomic): a cell that holds a few per cent of a cloud would
+      // otherwise serialise thousands of atomics on one address.
+      __shared__ int s_hkey[kHashSlots], s_hcnt[kHashSlots];
+      for (int h = tid; h < kHashSlots; h += kPartBlock) {
+        s_hkey[h] = -1;
+        s_hcnt[h] = 0;
+      }
+      __syncthreads();
+      int slot[kPartPerThread];
+#pragma unroll
+      for (int r = 0; r < kPartPerThread; ++r) {
+        slot[r] = -2;  // not a record of a crowded bin
+        if (bin[r] < 0) continue;
+        const int cb = bin[r] >> shift;
+        if (((s_crowd[cb >> 5] >> (cb & 31)) & 1u) == 0u) continue;
+        slot[r] = -1;  // no slot: own atomic
+        int h = (int)(((unsigned)bin[r] * 2654435761u) >> (32 - kHashBits));
+        for (int probe = 0; probe < kHashProbes; ++probe) {
+          const int old = atomicCAS(&s_hkey[h], -1, bin[r]);
+          if (old == -1 || old == bin[r]) {
+            slot[r] = h;
+            rank[r] = atomicAdd(&s_hcnt[h], 1);
+            break;
+          }
+          h = (h + 1) & (kHashSlots - 1);
+        }
+      }
+      __syncthreads();
+      constexpr int kSlotsPerThread = kHashSlots / kPartBlock;
+      int base[kSlotsPerThread];  // (two loops: a thread's device atomics are in flight together)
+#pragma unroll
+      for (int t = 0; t < kSlotsPerThread; ++t) {
+        const int h = tid + t * kPartBlock;
+        const int key = s_hkey[h];
+        base[t] = key >= 0 ? atomicAdd(fine + key, s_hcnt[h]) : 0;
+      }
+#pragma unroll
+      for (int t = 0; t < kSlotsPerThread; ++t) s_hcnt[tid + t * kPartBlock] = base[t];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < kPartPerThread; ++r) {
+        if (slot[r] >= 0) grank[pos[r]] = s_hcnt[slot[r]] + rank[r];
+        else if (slot[r] == -1) grank[pos[r]] = atomicAdd(fine + bin[r], 1);
+      }
+    }
+  }
+}
+
+// counter f of the sort pass lives at f + f / 32: a thread scanning a contiguous slice of counters does not keep
+// hitting one LDS bank
+__device__ __forceinline__ int fine_slot(int f) { return f + (f >> 5); }
+
+// SORT pass: workgroup (b mod gridDim.x) of (cloud, set) sorts coarse bin b by cell.  `refine` as in GridBuild.
+// A CROWDED bin (more than kCrowded records: a cluster, the dense end of a density gradient) would keep one workgroup
+// busy for hundreds of microseconds; the partition pass has already counted its records per cell and handed every
+// record its rank inside its cell (fine_count / rank arrays), so its slices of kCrowdedSlice records are placed by as
+// many workgroups as there are slices, without atomics: position = cell start (scan of the bin's cell counts, redone
+// per slice from L2) + rank.
+__global__ __launch_bounds__(kSortBlock) void grid_sort_kernel(GridWs ws, int P1, int P2, int refine) {
+  __shared__ int s_cnt[kFineMax + kFineMax / 32];
+  __shared__ int s_wsum[kSortBlock / kWave];
+  __shared__ int s_list[kCrowdedMax];
+  const int n = blockIdx.y, set = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const GridCloud g = ws.cloud[n];
+  const int len = set ? g.len1 : g.len2;
+  if (!g.use_grid || len <= 0) return;
+  const int shift = g.shift[set], nbin = g.nbin[set];
+  const int* __restrict__ cstart = ws.coarse_start + coarse_row(n, set);
+  int* __restrict__ cell_start = ws.cell_start + (int64_t)n * (ws.cell_cap + 1);
+  const float4* __restrict__ tmp = set ? ws.qtmp + (int64_t)n * P1 : ws.sorted_tmp + (int64_t)n * P2;
+  float4* __restrict__ out = set ? ws.qsorted + (int64_t)n * P1 : ws.sorted + (int64_t)n * (P2 + kSortedPad);
+  const int ncrowd = ws.crowded_count[n * 2 + set];  // (<= kCrowdedMax)
+  if (ncrowd > 0) {
+    if (tid < ncrowd) s_list[tid] = ws.crowded_list[(int64_t)(n * 2 + set) * kCrowdedMax + tid];
+    __syncthreads();
+  }
+  constexpr int kUnroll = 4;                // records in flight per thread (long bins)
+  constexpr int kKeep = 2048 / kSortBlock;  // records per thread a bin may have to stay in registers
+
+  // counts in s_cnt[0, nf) -> exclusive cursors (relative to the bin); `publish`: cell_start and the refined-cell
+  // marks of the bin's cells
+  auto scan_cells = [&](int f0, int nf, int start, int cnt, bool publish) {
+    const int per = (nf + kSortBlock - 1) / kSortBlock;
+    const int a0 = min(tid * per, nf), a1 = min(a0 + per, nf);
+    int sum = 0;
+    for (int f = a0; f < a1; ++f) sum += s_cnt[fine_slot(f)];
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int u = __shfl_up(inc, off, kWave);
+      if (lane >= off) inc += u;
+    }
+    if (lane == kWave - 1) s_wsum[wave] = inc;
+    __syncthreads();
+    int run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += s_wsum[w];
+    for (int f = a0; f < a1; ++f) {
+      const int c = s_cnt[fine_slot(f)];
+      s_cnt[fine_slot(f)] = run;
+      run += c;
+    }
+    __syncthreads();
+    if (publish && set == 0) {  // (coalesced: cell f of the bin by thread f)
+      for (int f = tid; f < nf; f += kSortBlock) {
+        const int e = s_cnt[fine_slot(f)];
+        const int c = (f + 1 < nf ? s_cnt[fine_slot(f + 1)] : cnt) - e;
+        cell_start[f0 + f] = start + e;
+        if (refine >= 0) {
+          int ref = -1;
+          if (refine > 0 && c > refine_threshold(ws.c_target)) {
+            int s = (int)ceilf(cbrtf((float)c / ws.c_target));
+            s = s < 2 ? 2 : (s > kRefineMaxS ? kRefineMaxS : s);
+            const int cells = s * s * s + 1;
+            const int idx = atomicAdd(ws.rcount + n, 1);
+            if (idx < ws.rdesc_cap) {
+              RefinedCell d{};  // count == 0: a descriptor without a table (pool exhausted), skipped by refine_build
+              const int off = atomicAdd(ws.pool_top + n, cells);
+              if (off + cells <= ws.pool_cap) {
+                d.start = start + e;
+                d.count = c;
+                d.s = s;
+                d.pool_off = off;
+                ref = idx;
+              }
+              ws.rdesc[(int64_t)n * ws.rdesc_cap + idx] = d;
+            }
+          }
+          ws.refine_ref[(int64_t)n * ws.cell_cap + f0 + f] = ref;
+        }
+      }
+      if (f0 + nf == g.ncell && tid == 0) cell_start[g.ncell] = start + cnt;  // (the cloud's last bin)
+    }
+  };
+
+  for (int b = blockIdx.x; b < nbin; b += gridDim.x) {
+    const int start = cstart[b], cnt = cstart[b + 1] - start;
+    if (cnt > kCrowded) {  // listed as crowded: done by slices below
+      bool listed = false;
+      for (int k = 0; k < ncrowd; ++k) listed = listed || s_list[k] == b;
+      if (listed) continue;
+    }
+    const int f0 = b << shift;
+    const int nf = min(1 << shift, g.ncell - f0);
+    for (int f = tid; f < nf; f += kSortBlock) s_cnt[fine_slot(f)] = 0;
+    __syncthreads();
+    auto fine_of = [&](const float4 p) {  // the same expression as the partition pass
+      int cx, cy, cz;
+      point_cells(g, p.x, p.y, p.z, cx, cy, cz);
+      return (cz * g.G[1] + cy) * g.G[0] + cx - f0;
+    };
+    // 1. histogram of the bin's cells.  A bin of up to 2048 records (the usual case) stays in registers with
+    //    the rank the LDS atomic handed out; a longer one is read twice.
+    const bool keep = cnt <= kKeep * kSortBlock;  // (workgroup-uniform)
+    float4 kp[kKeep];
+    int kf[kKeep], krank[kKeep];
+    if (keep) {
+#pragma unroll
+      for (int u = 0; u < kKeep; ++u) {
+        const int j = tid + u * kSortBlock;
+        kf[u] = -1;
+        if (j < cnt) {
+          kp[u] = tmp[start + j];
+          kf[u] = fine_of(kp[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kKeep; ++u)
+        if (kf[u] >= 0) krank[u] = atomicAdd(&s_cnt[fine_slot(kf[u])], 1);
+    } else {
+      for (int i0 = 0; i0 < cnt; i0 += kUnroll * kSortBlock) {  // (workgroup-uniform trip count: wave_add shuffles)
+        int f[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int j = i0 + tid + u * kSortBlock;
+          f[u] = -1;
+          if (j < cnt) f[u] = fine_of(tmp[start + j]);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) wave_add(s_cnt, fine_slot(f[u] < 0 ? 0 : f[u]), f[u] >= 0);
+      }
+    }
+    __syncthreads();
+    // 2. exclusive scan -> cell_start, refined-cell marks, cursors
+    scan_cells(f0, nf, start, cnt, true);
+    __syncthreads();
+    // 3. records to their final places
+    if (keep) {
+#pragma unroll
+      for (int u = 0; u < kKeep; ++u)
+        if (kf[u] >= 0) out[start + s_cnt[fine_slot(kf[u])] + krank[u]] = kp[u];
+    } else {
+      for (int i0 = 0; i0 < cnt; i0 += kUnroll * kSortBlock) {  // (second read of the bin: L2)
+        float4 p[kUnroll];
+        bool live[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int j = i0 + tid + u * kSortBlock;
+          live[u] = j < cnt;
+          p[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (live[u]) p[u] = tmp[start + j];
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int pos = wave_add(s_cnt, fine_slot(live[u] ? fine_of(p[u]) : 0), live[u]);
+          if (live[u]) out[start + pos] = p[u];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // crowded bins, by slices
+  const int* __restrict__ fine = ws.fine_count + (int64_t)(n * 2 + set) * ws.cell_cap;
+  const int* __restrict__ rank = set ? ws.qrank + (int64_t)n * P1 : ws.prank + (int64_t)n * P2;
+  for (int k = 0; k < ncrowd; ++k) {
+    const int b = s_list[k];
+    const int start = cstart[b], cnt = cstart[b + 1] - start;
+    const int f0 = b << shift;
+    const int nf = min(1 << shift, g.ncell - f0);
+    const int slices = (cnt + kCrowdedSlice - 1) / kCrowdedSlice;
+    for (int sl = blockIdx.x; sl < slices; sl += gridDim.x) {
+      for (int f = tid; f < nf; f += kSortBlock) s_cnt[fine_slot(f)] = fine[f0 + f];
+      __syncthreads();
+      scan_cells(f0, nf, start, cnt, sl == 0);
+      const int j1 = min(cnt, (sl + 1) * kCrowdedSlice);
+      for (int j = sl * kCrowdedSlice + tid; j < j1; j += kSortBlock) {
+        const float4 p = tmp[start + j];
+        int cx, cy, cz;
+        point_cells(g, p.x, p.y, p.z, cx, cy, cz);
+        const int f = (cz * g.G[1] + cy) * g.G[0] + cx - f0;
+        out[start + s_cnt[fine_slot(f)] + rank[start + j]] = p;
+      }
+      __syncthreads();
     }
   }
 }
@@ -630,12 +762,20 @@ size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, flo
   w.cloud = (GridCloud*)take(sizeof(GridCloud) * (size_t)N);
   w.chunk_prefix = (int*)take(sizeof(int) * (size_t)(N + 1));
   w.edges = (float*)take(sizeof(float) * (size_t)N * 3 * kEdgeStride);
-  w.cell_count = (int*)take(sizeof(int) * (size_t)N * cap);
-  w.qcell_count = (int*)take(sizeof(int) * (size_t)N * cap);  // adjacent to cell_count: one memset
   w.cell_start = (int*)take(sizeof(int) * (size_t)N * (cap + 1));
-  w.qcell_start = (int*)take(sizeof(int) * (size_t)N * (cap + 1));
+  w.coarse_count = (int*)take(sizeof(int) * (size_t)N * 2 * (kCoarseMax + 1));
+  w.coarse_cursor = (int*)take(sizeof(int) * (size_t)N * 2 * (kCoarseMax + 1));
+  w.coarse_start = (int*)take(sizeof(int) * (size_t)N * 2 * (kCoarseMax + 1));
+  w.coarse_ticket = (int*)take(sizeof(int) * (size_t)N * 2);
+  w.crowded_count = (int*)take(sizeof(int) * (size_t)N * 2);
+  w.crowded_list = (int*)take(sizeof(int) * (size_t)N * 2 * kCrowdedMax);
+  w.fine_count = (int*)take(sizeof(int) * (size_t)N * 2 * cap);
+  w.prank = (int*)take(sizeof(int) * (size_t)N * (size_t)P2);
+  w.qrank = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
+  w.order_count = (int*)take(sizeof(int) * (size_t)N * kOrderBins);
+  w.order_cursor = (int*)take(sizeof(int) * (size_t)N * kOrderBins);
   w.sorted = (float4*)take(sizeof(float4) * (size_t)N * (size_t)(P2 + kSortedPad));
-  w.qlist = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
+  w.qsorted = (float4*)take(sizeof(float4) * (size_t)N * (size_t)P1);
   w.fb_count = (int*)take(sizeof(int) * (size_t)N);
   w.fb_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.fb_kth = (unsigned*)take(sizeof(unsigned) * (size_t)N * (size_t)P1);
@@ -644,10 +784,8 @@ size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, flo
   w.fb3_count = (int*)take(sizeof(int) * (size_t)N);
   w.fb3_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.bbox = (unsigned*)take(sizeof(unsigned) * (size_t)N * 8);
-  w.scan_partial = (int*)take(sizeof(int) * (size_t)N * 2 * (size_t)((cap + kScanChunk - 1) / kScanChunk));
   w.grid_flag = (int*)take(sizeof(int) * (size_t)N);
-  w.rank1 = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
-  w.rank2 = (int*)take(sizeof(int) * (size_t)N * (size_t)P2);
+  w.qtmp = (float4*)take(sizeof(float4) * (size_t)N * (size_t)P1);
   w.rdesc_cap = (int)(P2 / 64 + 1);  // a refined cell holds more than refine_threshold() >= 64 points
   w.pool_cap = (int)(4 * P2 + 64);   // sum of (s^3 + 1) <= sum of (8 count / c + 9) over refined cells
   w.refine_ref = (int*)take(sizeof(int) * (size_t)N * cap);
@@ -666,29 +804,27 @@ size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, flo
 
 template <int D>
 static void build_d(const KnnArgs& a, const GridWs& ws, bool same, int refine) {
-  const int chunks = (ws.cell_cap + kScanChunk - 1) / kScanChunk;
-  const unsigned which = same ? 1u : 2u;  // points only / points and queries
-  const dim3 gb((unsigned)ceil_div(same ? a.P2 : (a.P2 > a.P1 ? a.P2 : a.P1), kBinTile), (unsigned)a.N, which);
-#define PO_BIN(SCT, QRY)                                                                                          \
-  hipLaunchKernelGGL((grid_bin_kernel<D, SCT, QRY>), gb, dim3(kBinBlock), 0, a.stream, a.p2, a.P2, a.p1, a.P1, a.K, \
-                     ws, a.idxs, a.dists)
-  if (same) PO_BIN(false, false);
-  else PO_BIN(false, true);
-  hipLaunchKernelGGL(grid_scan_partial_kernel, dim3((unsigned)chunks, (unsigned)a.N, which), dim3(kScanBlock), 0,
-                     a.stream, ws, chunks);
-  hipLaunchKernelGGL(grid_scan_offsets_kernel, dim3((unsigned)a.N, which), dim3(kScanBlock), 0, a.stream, ws, chunks);
-  hipLaunchKernelGGL(grid_scan_apply_kernel, dim3((unsigned)chunks, (unsigned)a.N, which), dim3(kScanBlock), 0,
-                     a.stream, ws, chunks, refine);
-  if (same) PO_BIN(true, false);
-  else PO_BIN(true, true);
-#undef PO_BIN
+  const unsigned sets = same ? 1u : 2u;  // points only / points and queries
+  const dim3 gp((unsigned)ceil_div(same ? a.P2 : (a.P2 > a.P1 ? a.P2 : a.P1), kPartTile), (unsigned)a.N, sets);
+#define PO_PART(SCT, QRY)                                                                                        \
+  hipLaunchKernelGGL((grid_partition_kernel<D, SCT, QRY>), gp, dim3(kPartBlock), 0, a.stream, a.p2, a.P2, a.p1,  \
+                     a.P1, a.K, ws, a.idxs, a.dists)
+  if (same) {
+    PO_PART(false, false);
+    PO_PART(true, false);
+  } else {
+    PO_PART(false, true);
+    PO_PART(true, true);
+  }
+#undef PO_PART
+  // sort workgroups per (cloud, set): enough of them to fill the chip when the batch is small
+  int64_t wgs = 8192 / (a.N * (int64_t)sets);
+  wgs = wgs < 16 ? 16 : (wgs > kCoarseMax ? kCoarseMax : wgs);
+  hipLaunchKernelGGL(grid_sort_kernel, dim3((unsigned)wgs, (unsigned)a.N, sets), dim3(kSortBlock), 0, a.stream, ws,
+                     (int)a.P1, (int)a.P2, refine);
 }
 
 int grid_build(const KnnArgs& a, const GridWs& ws, const GridBuild& b) {
-  // histogram buffers (cell_count and qcell_count are adjacent) start at zero
-  const size_t zero_bytes = b.same ? (size_t)((char*)ws.qcell_count - (char*)ws.cell_count)
-                                   : (size_t)((char*)ws.cell_start - (char*)ws.cell_count);
-  if (hipMemsetAsync(ws.cell_count, 0, zero_bytes, a.stream) != hipSuccess) return check_launch("grid memset");
   hipLaunchKernelGGL(grid_bbox_init_kernel, dim3((unsigned)ceil_div(a.N * 8, 256)), dim3(256), 0, a.stream, ws.bbox,
                      (int)a.N);
   hipLaunchKernelGGL(grid_bbox_kernel, dim3((unsigned)ceil_div(a.P2, kBboxBlock * kBboxPerThread), (unsigned)a.N),

@@ -17,7 +17,7 @@
 
 namespace pointops {
 
-constexpr int kRefineBlock = 256;
+constexpr int kRefineBlock = 1024;
 constexpr int kRefineWgs = 8;  // workgroups per cloud walking the cloud's list of refined cells (each claims 128 KB
                                // of LDS: 256 of them are one round of the chip, and an empty list costs one round)
 

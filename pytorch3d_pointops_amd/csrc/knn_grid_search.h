@@ -190,7 +190,7 @@ template <int D, int KC, int NORM>
 __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const int* __restrict__ chunk_prefix,
     const float* __restrict__ edges, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
-    const int* __restrict__ qlist, int* __restrict__ fb_count, int* __restrict__ fb_list,
+    const float4* __restrict__ qsorted, int* __restrict__ fb_count, int* __restrict__ fb_list,
     unsigned* __restrict__ fb_kth, int* __restrict__ box_count, int* __restrict__ box_list, int defer_limit,
     int cell_cap, int P1, int P2, int K, int N, int64_t* __restrict__ idxs, float* __restrict__ dists) {
   using Cfg = LaneCfg<KC>;
@@ -227,17 +227,12 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
     const float4* __restrict__ sp = sorted + (int64_t)n * (P2 + kSortedPad);
     int qi = 0;
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-    if (g.same) {  // the queries are the points: the cell-sorted records are the query order (coalesced)
-      if (active) {
-        const float4 q = sp[c0 + lane];
-        qx = q.x;
-        qy = q.y;
-        qz = q.z;
-        qi = __float_as_int(q.w);
-      }
-    } else if (active) {
-      qi = qlist[(int64_t)n * P1 + c0 + lane];
-      load_point3<D>(p1 + ((int64_t)n * P1 + qi) * D, qx, qy, qz);
+    if (active) {  // query records in cell order (the point records themselves when the queries are the points)
+      const float4 q = (g.same ? sp : qsorted + (int64_t)n * P1)[c0 + lane];
+      qx = q.x;
+      qy = q.y;
+      qz = q.z;
+      qi = __float_as_int(q.w);
     }
     int cx, cy, cz;
     point_cells(g, qx, qy, qz, cx, cy, cz);
@@ -693,7 +688,7 @@ static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
   const int wgs = 256 * 32;  // one wave64 per workgroup, up to 32 waves per CU resident
   hipLaunchKernelGGL((knn_grid_lane_kernel<D, KC, NORM>), dim3((unsigned)wgs), dim3(kGridWave), 0, a.stream, a.p1,
                      (const GridCloud*)ws.cloud, (const int*)ws.chunk_prefix, (const float*)ws.edges,
-                     (const int*)ws.cell_start, (const float4*)ws.sorted, (const int*)ws.qlist, ws.fb_count,
+                     (const int*)ws.cell_start, (const float4*)ws.sorted, (const float4*)ws.qsorted, ws.fb_count,
                      ws.fb_list, ws.fb_kth, ws.box_count, ws.box_list, kDeferFactor * refine_threshold(ws.c_target),
                      ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
   if constexpr (KC <= 32) if (quad) {
