@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float*
   const GridCloud g = ws.cloud[n];  // wave-uniform
   const int set = IS_QUERY ? 1 : 0;
   const int len = IS_QUERY ? g.len1 : g.len2;
-  const int shift = g.shift[set], nbin = g.nbin[set];
+  const int shift = IS_QUERY ? g.shift[1] : g.shift[0], nbin = IS_QUERY ? g.nbin[1] : g.nbin[0];
   int* __restrict__ gcount = ws.coarse_count + coarse_row(n, set);
   int* __restrict__ gcursor = ws.coarse_cursor + coarse_row(n, set);
   int* __restrict__ gstart = ws.coarse_start + coarse_row(n, set);
@@ -568,7 +568,9 @@ __global__ __launch_bounds__(kSortBlock) void grid_sort_kernel(GridWs ws, int P1
   const GridCloud g = ws.cloud[n];
   const int len = set ? g.len1 : g.len2;
   if (!g.use_grid || len <= 0) return;
-  const int shift = g.shift[set], nbin = g.nbin[set];
+  // (selects, not g.shift[set]: a dynamically indexed member sends the whole struct through scratch memory, and a
+  // kernel that uses scratch costs tens of microseconds per launch)
+  const int shift = set ? g.shift[1] : g.shift[0], nbin = set ? g.nbin[1] : g.nbin[0];
   const int* __restrict__ cstart = ws.coarse_start + coarse_row(n, set);
   int* __restrict__ cell_start = ws.cell_start + (int64_t)n * (ws.cell_cap + 1);
   const float4* __restrict__ tmp = set ? ws.qtmp + (int64_t)n * P1 : ws.sorted_tmp + (int64_t)n * P2;
@@ -578,7 +580,6 @@ __global__ __launch_bounds__(kSortBlock) void grid_sort_kernel(GridWs ws, int P1
     if (tid < ncrowd) s_list[tid] = ws.crowded_list[(int64_t)(n * 2 + set) * kCrowdedMax + tid];
     __syncthreads();
   }
-  constexpr int kUnroll = 4;                // records in flight per thread (long bins)
   constexpr int kKeep = 2048 / kSortBlock;  // records per thread a bin may have to stay in registers
 
   // counts in s_cnt[0, nf) -> exclusive cursors (relative to the bin); `publish`: cell_start and the refined-cell
@@ -617,16 +618,16 @@ __global__ __launch_bounds__(kSortBlock) void grid_sort_kernel(GridWs ws, int P1
             const int cells = s * s * s + 1;
             const int idx = atomicAdd(ws.rcount + n, 1);
             if (idx < ws.rdesc_cap) {
-              RefinedCell d{};  // count == 0: a descriptor without a table (pool exhausted), skipped by refine_build
+              // count == 0: a descriptor without a table (pool exhausted), skipped by refine_build.  (Field by field:
+              // a RefinedCell temporary gave the kernel a private segment.)
               const int off = atomicAdd(ws.pool_top + n, cells);
-              if (off + cells <= ws.pool_cap) {
-                d.start = start + e;
-                d.count = c;
-                d.s = s;
-                d.pool_off = off;
-                ref = idx;
-              }
-              ws.rdesc[(int64_t)n * ws.rdesc_cap + idx] = d;
+              const bool fits = off + cells <= ws.pool_cap;
+              RefinedCell* __restrict__ dp = ws.rdesc + (int64_t)n * ws.rdesc_cap + idx;
+              dp->start = fits ? start + e : 0;
+              dp->count = fits ? c : 0;
+              dp->s = fits ? s : 0;
+              dp->pool_off = fits ? off : 0;
+              if (fits) ref = idx;
             }
           }
           ws.refine_ref[(int64_t)n * ws.cell_cap + f0 + f] = ref;
@@ -671,16 +672,19 @@ __global__ __launch_bounds__(kSortBlock) void grid_sort_kernel(GridWs ws, int P1
       for (int u = 0; u < kKeep; ++u)
         if (kf[u] >= 0) krank[u] = atomicAdd(&s_cnt[fine_slot(kf[u])], 1);
     } else {
-      for (int i0 = 0; i0 < cnt; i0 += kUnroll * kSortBlock) {  // (workgroup-uniform trip count: wave_add shuffles)
-        int f[kUnroll];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          const int j = i0 + tid + u * kSortBlock;
-          f[u] = -1;
-          if (j < cnt) f[u] = fine_of(tmp[start + j]);
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) wave_add(s_cnt, fine_slot(f[u] < 0 ? 0 : f[u]), f[u] >= 0);
+      // (workgroup-uniform trip count: wave_add shuffles)
+      for (int i0 = 0; i0 < cnt; i0 += 4 * kSortBlock) {
+        const int j = i0 + tid;
+        const bool l0 = j < cnt, l1 = j + kSortBlock < cnt, l2 = j + 2 * kSortBlock < cnt, l3 = j + 3 * kSortBlock < cnt;
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4 p0 = l0 ? tmp[start + j] : z;
+        const float4 p1 = l1 ? tmp[start + j + kSortBlock] : z;
+        const float4 p2 = l2 ? tmp[start + j + 2 * kSortBlock] : z;
+        const float4 p3 = l3 ? tmp[start + j + 3 * kSortBlock] : z;
+        wave_add(s_cnt, fine_slot(l0 ? fine_of(p0) : 0), l0);
+        wave_add(s_cnt, fine_slot(l1 ? fine_of(p1) : 0), l1);
+        wave_add(s_cnt, fine_slot(l2 ? fine_of(p2) : 0), l2);
+        wave_add(s_cnt, fine_slot(l3 ? fine_of(p3) : 0), l3);
       }
     }
     __syncthreads();
@@ -693,21 +697,22 @@ __global__ __launch_bounds__(kSortBlock) void grid_sort_kernel(GridWs ws, int P1
       for (int u = 0; u < kKeep; ++u)
         if (kf[u] >= 0) out[start + s_cnt[fine_slot(kf[u])] + krank[u]] = kp[u];
     } else {
-      for (int i0 = 0; i0 < cnt; i0 += kUnroll * kSortBlock) {  // (second read of the bin: L2)
-        float4 p[kUnroll];
-        bool live[kUnroll];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          const int j = i0 + tid + u * kSortBlock;
-          live[u] = j < cnt;
-          p[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          if (live[u]) p[u] = tmp[start + j];
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          const int pos = wave_add(s_cnt, fine_slot(live[u] ? fine_of(p[u]) : 0), live[u]);
-          if (live[u]) out[start + pos] = p[u];
-        }
+      for (int i0 = 0; i0 < cnt; i0 += 4 * kSortBlock) {  // (second read of the bin: L2)
+        const int j = i0 + tid;
+        const bool l0 = j < cnt, l1 = j + kSortBlock < cnt, l2 = j + 2 * kSortBlock < cnt, l3 = j + 3 * kSortBlock < cnt;
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4 p0 = l0 ? tmp[start + j] : z;
+        const float4 p1 = l1 ? tmp[start + j + kSortBlock] : z;
+        const float4 p2 = l2 ? tmp[start + j + 2 * kSortBlock] : z;
+        const float4 p3 = l3 ? tmp[start + j + 3 * kSortBlock] : z;
+        const int q0 = wave_add(s_cnt, fine_slot(l0 ? fine_of(p0) : 0), l0);
+        const int q1 = wave_add(s_cnt, fine_slot(l1 ? fine_of(p1) : 0), l1);
+        const int q2 = wave_add(s_cnt, fine_slot(l2 ? fine_of(p2) : 0), l2);
+        const int q3 = wave_add(s_cnt, fine_slot(l3 ? fine_of(p3) : 0), l3);
+        if (l0) out[start + q0] = p0;
+        if (l1) out[start + q1] = p1;
+        if (l2) out[start + q2] = p2;
+        if (l3) out[start + q3] = p3;
       }
     }
     __syncthreads();
@@ -818,8 +823,11 @@ static void build_d(const KnnArgs& a, const GridWs& ws, bool same, int refine) {
   }
 #undef PO_PART
   // sort workgroups per (cloud, set): enough of them to fill the chip when the batch is small
+  // (a cloud of P entries has at most P / kCoarsePoints + 1 bins)
+  const int64_t bins = (same ? a.P2 : (a.P2 > a.P1 ? a.P2 : a.P1)) / kCoarsePoints + 2;
   int64_t wgs = 8192 / (a.N * (int64_t)sets);
   wgs = wgs < 16 ? 16 : (wgs > kCoarseMax ? kCoarseMax : wgs);
+  wgs = wgs > bins ? bins : wgs;
   hipLaunchKernelGGL(grid_sort_kernel, dim3((unsigned)wgs, (unsigned)a.N, sets), dim3(kSortBlock), 0, a.stream, ws,
                      (int)a.P1, (int)a.P2, refine);
 }
