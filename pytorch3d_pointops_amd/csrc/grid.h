@@ -13,9 +13,9 @@ constexpr int kGMax = 1024;          // cells per dimension cap (edge table size
 constexpr int kEdgeStride = kGMax + 2;
 constexpr int kGridWave = 64;
 constexpr int kNumXcd = 8;           // MI355X: 8 XCDs x 32 CUs, private 4 MB L2 each
-constexpr int kCoarseMax = 2048;     // coarse bins per cloud and set of the two-level sort
+constexpr int kCoarseMax = 1024;     // micro-bins (and bins) per cloud and set of the two-level sort
 constexpr int kCrowdedMax = 64;      // crowded coarse bins listed per cloud and set (further ones: one workgroup each)
-constexpr int kFineLogMax = 12;      // cells per coarse bin <= 4096
+constexpr int kFineLogMax = 12;      // cells per bin <= 4096
 constexpr int kOrderG = 16, kOrderBins = kOrderG * kOrderG * kOrderG;  // ball query: coarse cells of the scan-mode query order
 constexpr int kSortedPad = 8;        // records of padding behind every cloud's sorted array: record P2 is a NaN
                                      // sentinel (never a candidate); group loads of the lane searches may run
@@ -29,7 +29,7 @@ struct GridCloud {
   int len1, len2;
   int use_grid;
   int same;  // 1 = the queries ARE the points (p1 == p2, lengths1 == lengths2): the point sort is the query order
-  int shift[2], nbin[2];  // two-level sort (grid_build.hip): coarse bin = cell id >> shift, per set (0 points, 1 queries)
+  int mshift, nmicro;  // two-level sort (grid_build.hip): micro-bin = cell id >> mshift, nmicro <= kCoarseMax of them
 };
 
 // A REFINED cell: a level-0 cell holding far more points than the target gets its own s x s x s sub-grid over the
@@ -47,9 +47,12 @@ struct GridWs {
   int* chunk_prefix;  // N + 1     64-query chunks of the clouds before cloud n
   float* edges;       // N * 3 * kEdgeStride
   int* cell_start;    // N * (cell_cap + 1)
-  int* coarse_count;  // N * 2 * (kCoarseMax + 1)   entries per coarse bin (set 0 points, 1 queries)
-  int* coarse_cursor; // N * 2 * (kCoarseMax + 1)   groups handed out so far
-  int* coarse_start;  // N * 2 * (kCoarseMax + 1)   exclusive scan of coarse_count
+  int* coarse_count;  // N * 2 * (kCoarseMax + 1)   entries per micro-bin (set 0 points, 1 queries)
+  int* bin_of;        // N * 2 * (kCoarseMax + 1)   micro-bin -> bin (consecutive micro-bins with ~kCoarsePoints entries)
+  int* bin_first;     // N * 2 * (kCoarseMax + 1)   bin -> its first micro-bin; [nbins] = nmicro
+  int* nbins;         // N * 2
+  int* coarse_cursor; // N * 2 * (kCoarseMax + 1)   per bin: entries handed out so far
+  int* coarse_start;  // N * 2 * (kCoarseMax + 1)   per bin: first entry; [nbins] = entries of the set
   float4* sorted;     // N * (P2 + kSortedPad)   (x, y, z, idx bits) by cell
   int* coarse_ticket; // N * 2           tiles of the count launch that have finished
   int* crowded_count; // N * 2           crowded coarse bins (<= kCrowdedMax), listed in

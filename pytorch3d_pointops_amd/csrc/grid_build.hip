@@ -217,17 +217,11 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     g.ncell = G[0] * G[1] * G[2];
     g.len1 = len1;
     g.len2 = len2;
-    // coarse bins of the two-level sort: cell id >> shift, with ~kCoarsePoints entries per bin and <= kCoarseMax bins
-    for (int set = 0; set < 2; ++set) {
-      const long long len = set ? len1 : len2;
-      int shift = 0;
-      while (shift < kFineLogMax && ((((g.ncell - 1) >> shift) + 1 > kCoarseMax) ||
-                                     (len << shift) < (long long)kCoarsePoints * g.ncell))
-        ++shift;
-      g.shift[set] = shift;
-      g.nbin[set] = ((g.ncell - 1) >> shift) + 1;
-      if (g.nbin[set] > kCoarseMax) ok = false;
-    }
+    // micro-bins of the two-level sort: cell id >> mshift, at most kCoarseMax of them
+    g.mshift = 0;
+    while (((g.ncell - 1) >> g.mshift) + 1 > kCoarseMax) ++g.mshift;
+    g.nmicro = ((g.ncell - 1) >> g.mshift) + 1;
+    if (g.mshift > kFineLogMax) ok = false;
     g.use_grid = ok ? 1 : 0;
     g.same = same;
     s_g = g;
@@ -249,6 +243,7 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
   if (tid < 2) {
     ws.coarse_ticket[n * 2 + tid] = 0;
     ws.crowded_count[n * 2 + tid] = 0;
+    ws.nbins[n * 2 + tid] = 0;
   }
   __syncthreads();
   if (s_g.use_grid) {
@@ -293,25 +288,27 @@ __global__ void grid_prefix_kernel(GridWs ws, int N) {  // one wave
 // a direct counting sort costs one scattered device-scope atomic per point (they execute at the memory side,
 // ~2e10/s chip-wide: 105 us for the 2.4 M points and queries of the K=1 / chamfer case) and a 16-byte store at a
 // random position of a megabyte-sized array (4x write amplification).  Instead:
-//   PARTITION  (count, then scatter; tiles of 8192 entries) by COARSE bin = cell id >> shift, a contiguous range of
-//              2^shift cells with ~1000-2000 entries (<= 2048 bins per cloud: an LDS histogram per tile, ONE device atomic
-//              per non-empty (tile, bin), runs of tens to hundreds of records written together);
-//   SORT       one workgroup per coarse bin: histogram of the bin's cells in LDS, exclusive scan -> the bin's slice
+//   PARTITION  count: tiles of 16384 entries count MICRO-BINS (cell id >> mshift, <= 1024 per cloud) in LDS and add
+//              each non-empty one to the cloud's counters with ONE device atomic; the last tile to finish groups
+//              consecutive micro-bins into BINS of ~1000-2000 entries and <= 4096 cells (so the bins follow the data: a
+//              surface or a cluster occupies few micro-bins) and lists the crowded ones;
+//              scatter: records grouped by bin (runs of tens to hundreds of records written together);
+//   SORT       one workgroup per bin: histogram of the bin's cells in LDS, exclusive scan -> the bin's slice
 //              of cell_start (and the refined-cell bookkeeping), then the records move to their final place inside the
 //              bin's own compact range of the sorted array (second read from L2).
-// No per-cell global counters, no global scans, no memset.  A crowded bin (a cluster) is simply a long loop of one
-// workgroup.  PAD_ROWS: the count launch also writes the rows that get no search (zeros / -1 for padded queries) and
-// lists the queries of clouds without a usable grid for the whole-cloud scan.
+// No per-cell global counters, no global scans, no memset.  PAD_ROWS: the count launch also writes the rows that get
+// no search (zeros / -1 for padded queries) and lists the queries of clouds without a usable grid for the whole-cloud
+// scan.
 // ---------------------------------------------------------------------------
 constexpr int kPartBlock = 1024;
-constexpr int kPartPerThread = 8;  // tile of 8192 entries
-constexpr int kPartTile = kPartBlock * kPartPerThread;
+constexpr int kCountPerThread = 16;   // count launch: tiles of 16384 entries (half the device atomics of 8192)
+constexpr int kScatterPerThread = 8;  // scatter launch: tiles of 8192 entries (the records stay in registers)
 constexpr int kSortBlock = 256;  // (512 / 1024 threads: 89 / 157 us instead of 62 us for the cfg2 sort pass)
 constexpr int kHashBits = 12, kHashSlots = 1 << kHashBits, kHashProbes = 8;  // partition pass: cells of crowded bins
 constexpr int kCrowded = 8192;       // records from which a coarse bin is CROWDED: sorted by slices (grid_sort_kernel)
 constexpr int kCrowdedSlice = 4096;  // records per slice
 constexpr int kFineMax = 1 << kFineLogMax;  // cells per coarse bin cap: the LDS counters of one sort workgroup
-static_assert(kCoarseMax == 2 * kPartBlock, "the partition pass scans two coarse counters per thread");
+static_assert(kCoarseMax == kPartBlock, "the count launch's last tile scans one micro-bin per thread");
 
 // atomicAdd(&counter[slot], 1) of every live lane of a wave; when all of them name the SAME counter (a bin whose
 // records sit in one cell: 64 LDS atomics on one address serialise) they spend one atomic.  Returns what the lane's
@@ -338,8 +335,11 @@ __global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float*
                                                                  const float* __restrict__ p1, int P1, int K,
                                                                  GridWs ws, int64_t* __restrict__ idxs,
                                                                  float* __restrict__ dists) {
-  __shared__ int s_hist[kCoarseMax];   // entries of this tile per coarse bin; then the base of the tile's group
-  __shared__ int s_start[kCoarseMax];  // SCATTER: exclusive scan of the cloud's coarse counts
+  constexpr int kPartPerThread = SCATTER ? kScatterPerThread : kCountPerThread;
+  constexpr int kPartTile = kPartBlock * kPartPerThread;
+  __shared__ int s_hist[kCoarseMax];   // entries of this tile per micro-bin / per bin; then the base of the tile's group
+  __shared__ int s_start[kCoarseMax];  // SCATTER: starts of the bins (count launch, last tile: of the micro-bins)
+  __shared__ int s_group[SCATTER ? kCoarseMax : 1];  // SCATTER: micro-bin -> bin
   __shared__ int s_wsum[kPartBlock / kWave];
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
@@ -350,10 +350,12 @@ __global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float*
   const GridCloud g = ws.cloud[n];  // wave-uniform
   const int set = IS_QUERY ? 1 : 0;
   const int len = IS_QUERY ? g.len1 : g.len2;
-  const int shift = IS_QUERY ? g.shift[1] : g.shift[0], nbin = IS_QUERY ? g.nbin[1] : g.nbin[0];
-  int* __restrict__ gcount = ws.coarse_count + coarse_row(n, set);
-  int* __restrict__ gcursor = ws.coarse_cursor + coarse_row(n, set);
-  int* __restrict__ gstart = ws.coarse_start + coarse_row(n, set);
+  const int mshift = g.mshift, nmicro = g.nmicro;
+  int* __restrict__ gcount = ws.coarse_count + coarse_row(n, set);    // per micro-bin
+  int* __restrict__ gcursor = ws.coarse_cursor + coarse_row(n, set);  // per bin
+  int* __restrict__ gstart = ws.coarse_start + coarse_row(n, set);    // per bin
+  int* __restrict__ gbinof = ws.bin_of + coarse_row(n, set);          // micro-bin -> bin
+  int* __restrict__ gfirst = ws.bin_first + coarse_row(n, set);       // bin -> its first micro-bin
   const int i0 = blockIdx.x * kPartTile + tid;
   if (blockIdx.x * kPartTile >= P) return;
 
@@ -379,37 +381,20 @@ __global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float*
   }
   if (!g.use_grid || blockIdx.x * kPartTile >= len) return;
 
-  for (int b = tid; b < nbin; b += kPartBlock) s_hist[b] = 0;
+  const int nb = SCATTER ? ws.nbins[n * 2 + set] : nmicro;  // counters of this launch: bins / micro-bins
+  for (int b = tid; b < nb; b += kPartBlock) s_hist[b] = 0;
   if (SCATTER) {
-    // exclusive scan of the cloud's coarse counts (every tile redoes it: <= 2048 counters from L2)
-    const int v0 = 2 * tid < nbin ? gcount[2 * tid] : 0;
-    const int v1 = 2 * tid + 1 < nbin ? gcount[2 * tid + 1] : 0;
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
-    int inc = v0 + v1;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const int u = __shfl_up(inc, off, kWave);
-      if (lane >= off) inc += u;
-    }
-    if (lane == kWave - 1) s_wsum[wave] = inc;
-    __syncthreads();
-    int excl = inc - v0 - v1;
-    for (int w = 0; w < wave; ++w) excl += s_wsum[w];
-    s_start[2 * tid] = excl;
-    s_start[2 * tid + 1] = excl + v0;
-    if (blockIdx.x == 0) {  // the table the sort pass reads: starts of the bins and the total behind them
-      gstart[2 * tid] = excl;
-      gstart[2 * tid + 1] = excl + v0;
-      if (tid == kPartBlock - 1) gstart[kCoarseMax] = excl + v0 + v1;
-    }
+    for (int m = tid; m < nmicro; m += kPartBlock) s_group[m] = gbinof[m];
+    for (int b = tid; b < nb; b += kPartBlock) s_start[b] = gstart[b];
   }
   __syncthreads();
-  int bin[kPartPerThread], rank[kPartPerThread];
+  int bin[kPartPerThread], key[kPartPerThread], rank[kPartPerThread];
   float px[kPartPerThread], py[kPartPerThread], pz[kPartPerThread];
 #pragma unroll
   for (int r = 0; r < kPartPerThread; ++r) {
     const int i = i0 + r * kPartBlock;
     bin[r] = -1;
+    key[r] = 0;
     rank[r] = 0;
     if (i < len) {
       float x, y, z;
@@ -417,16 +402,18 @@ __global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float*
       int cx, cy, cz;
       point_cells(g, x, y, z, cx, cy, cz);
       bin[r] = (cz * g.G[1] + cy) * g.G[0] + cx;
+      key[r] = bin[r] >> mshift;
       if (SCATTER) {
+        key[r] = s_group[key[r]];
         px[r] = x;
         py[r] = y;
         pz[r] = z;
       }
-      rank[r] = atomicAdd(&s_hist[bin[r] >> shift], 1);  // LDS atomic: rank inside (tile, coarse bin)
+      rank[r] = atomicAdd(&s_hist[key[r]], 1);  // LDS atomic: rank inside (tile, counter)
     }
   }
   __syncthreads();
-  for (int b = tid; b < nbin; b += kPartBlock) {
+  for (int b = tid; b < nb; b += kPartBlock) {
     const int c = s_hist[b];
     if (c > 0) {
       if (!SCATTER) {
@@ -454,22 +441,70 @@ __global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float*
     }
     __syncthreads();
     if (s_last) {  // (workgroup-uniform)
-      for (int b = tid; b < nbin; b += kPartBlock) {
-        const int c = __hip_atomic_load(gcount + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // BINS: consecutive micro-bins whose first record falls into the same block of kCoarsePoints records of the
+      // cloud's cell order and that lie in the same block of kFineMax cells.
+      const int lane = tid & (kWave - 1), wave = tid / kWave;
+      auto scan1 = [&](int v, int& total) {  // exclusive prefix of v over the workgroup (one value per thread)
+        int inc = v;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+          const int u = __shfl_up(inc, off, kWave);
+          if (lane >= off) inc += u;
+        }
+        __syncthreads();  // (s_wsum free again)
+        if (lane == kWave - 1) s_wsum[wave] = inc;
+        __syncthreads();
+        int excl = inc - v;
+        total = 0;
+        for (int w = 0; w < kPartBlock / kWave; ++w) {
+          if (w < wave) excl += s_wsum[w];
+          total += s_wsum[w];
+        }
+        return excl;
+      };
+      const int m = tid;
+      const int v = m < nmicro ? __hip_atomic_load(gcount + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      int total;
+      const int e = scan1(v, total);  // records before the micro-bin
+      s_start[m] = e;
+      __syncthreads();
+      const int span = kFineMax >> mshift;  // micro-bins a bin may cover
+      int o = 0;                            // micro-bin m opens a new bin
+      if (m < nmicro) {
+        o = 1;
+        if (m > 0) {
+          const int ep = s_start[m - 1];
+          o = ((e / kCoarsePoints) != (ep / kCoarsePoints) || (m / span) != ((m - 1) / span)) ? 1 : 0;
+        }
+      }
+      int nbins;
+      const int b = scan1(o, nbins) + o - 1;  // bin of the micro-bin
+      if (m < nmicro) gbinof[m] = b;
+      if (o) {
+        gfirst[b] = m;
+        gstart[b] = e;
+        s_hist[b] = e;  // (the tile's histogram is no longer needed: bin starts, for the crowded list)
+      }
+      if (tid == 0) {
+        gfirst[nbins] = nmicro;
+        gstart[nbins] = total;
+        ws.nbins[n * 2 + set] = nbins;
+      }
+      __syncthreads();
+      for (int b = tid; b < nbins; b += kPartBlock) {
+        const int c = (b + 1 < nbins ? s_hist[b + 1] : total) - s_hist[b];
         if (c > kCrowded) {
           const int k = atomicAdd(&s_ncrowd, 1);
-          if (k < kCrowdedMax) {
-            clist[k] = b;
-            s_hist[k] = b;  // (the tile's histogram is no longer needed)
-          }
+          if (k < kCrowdedMax) clist[k] = b;
         }
       }
       __syncthreads();
       const int nc = min(s_ncrowd, kCrowdedMax);
       if (tid == 0) ws.crowded_count[n * 2 + set] = nc;
-      for (int k = 0; k < nc; ++k) {
-        const int f0 = s_hist[k] << shift;
-        const int nf = min(1 << shift, g.ncell - f0);
+      for (int k = 0; k < nc; ++k) {  // (clist and gfirst: this workgroup's own writes, behind the barrier)
+        const int b = clist[k];
+        const int f0 = gfirst[b] << mshift;
+        const int nf = min((gfirst[b + 1] - gfirst[b]) << mshift, g.ncell - f0);
         for (int f = tid; f < nf; f += kPartBlock) fine[f0 + f] = 0;
       }
     }
@@ -493,7 +528,7 @@ __global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float*
       pos[r] = -1;
       if (bin[r] >= 0) {
         const int i = i0 + r * kPartBlock;
-        pos[r] = s_hist[bin[r] >> shift] + rank[r];
+        pos[r] = s_hist[key[r]] + rank[r];
         (IS_QUERY ? ws.qtmp : ws.sorted_tmp)[(int64_t)n * P + pos[r]] =
             make_float4(px[r], py[r], pz[r], __int_as_float(i));
       }
@@ -514,7 +549,7 @@ __global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float*
       for (int r = 0; r < kPartPerThread; ++r) {
         slot[r] = -2;  // not a record of a crowded bin
         if (bin[r] < 0) continue;
-        const int cb = bin[r] >> shift;
+        const int cb = key[r];
         if (((s_crowd[cb >> 5] >> (cb & 31)) & 1u) == 0u) continue;
         slot[r] = -1;  // no slot: own atomic
         int h = (int)(((unsigned)bin[r] * 2654435761u) >> (32 - kHashBits));
@@ -568,9 +603,8 @@ __global__ __launch_bounds__(kSortBlock) void grid_sort_kernel(GridWs ws, int P1
   const GridCloud g = ws.cloud[n];
   const int len = set ? g.len1 : g.len2;
   if (!g.use_grid || len <= 0) return;
-  // (selects, not g.shift[set]: a dynamically indexed member sends the whole struct through scratch memory, and a
-  // kernel that uses scratch costs tens of microseconds per launch)
-  const int shift = set ? g.shift[1] : g.shift[0], nbin = set ? g.nbin[1] : g.nbin[0];
+  const int mshift = g.mshift, nbin = ws.nbins[n * 2 + set];
+  const int* __restrict__ bfirst = ws.bin_first + coarse_row(n, set);
   const int* __restrict__ cstart = ws.coarse_start + coarse_row(n, set);
   int* __restrict__ cell_start = ws.cell_start + (int64_t)n * (ws.cell_cap + 1);
   const float4* __restrict__ tmp = set ? ws.qtmp + (int64_t)n * P1 : ws.sorted_tmp + (int64_t)n * P2;
@@ -644,8 +678,8 @@ __global__ __launch_bounds__(kSortBlock) void grid_sort_kernel(GridWs ws, int P1
       for (int k = 0; k < ncrowd; ++k) listed = listed || s_list[k] == b;
       if (listed) continue;
     }
-    const int f0 = b << shift;
-    const int nf = min(1 << shift, g.ncell - f0);
+    const int f0 = bfirst[b] << mshift;
+    const int nf = min((bfirst[b + 1] - bfirst[b]) << mshift, g.ncell - f0);
     for (int f = tid; f < nf; f += kSortBlock) s_cnt[fine_slot(f)] = 0;
     __syncthreads();
     auto fine_of = [&](const float4 p) {  // the same expression as the partition pass
@@ -724,8 +758,8 @@ __global__ __launch_bounds__(kSortBlock) void grid_sort_kernel(GridWs ws, int P1
   for (int k = 0; k < ncrowd; ++k) {
     const int b = s_list[k];
     const int start = cstart[b], cnt = cstart[b + 1] - start;
-    const int f0 = b << shift;
-    const int nf = min(1 << shift, g.ncell - f0);
+    const int f0 = bfirst[b] << mshift;
+    const int nf = min((bfirst[b + 1] - bfirst[b]) << mshift, g.ncell - f0);
     const int slices = (cnt + kCrowdedSlice - 1) / kCrowdedSlice;
     for (int sl = blockIdx.x; sl < slices; sl += gridDim.x) {
       for (int f = tid; f < nf; f += kSortBlock) s_cnt[fine_slot(f)] = fine[f0 + f];
@@ -771,6 +805,9 @@ size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, flo
   w.coarse_count = (int*)take(sizeof(int) * (size_t)N * 2 * (kCoarseMax + 1));
   w.coarse_cursor = (int*)take(sizeof(int) * (size_t)N * 2 * (kCoarseMax + 1));
   w.coarse_start = (int*)take(sizeof(int) * (size_t)N * 2 * (kCoarseMax + 1));
+  w.bin_of = (int*)take(sizeof(int) * (size_t)N * 2 * (kCoarseMax + 1));
+  w.bin_first = (int*)take(sizeof(int) * (size_t)N * 2 * (kCoarseMax + 1));
+  w.nbins = (int*)take(sizeof(int) * (size_t)N * 2);
   w.coarse_ticket = (int*)take(sizeof(int) * (size_t)N * 2);
   w.crowded_count = (int*)take(sizeof(int) * (size_t)N * 2);
   w.crowded_list = (int*)take(sizeof(int) * (size_t)N * 2 * kCrowdedMax);
@@ -810,10 +847,12 @@ size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, flo
 template <int D>
 static void build_d(const KnnArgs& a, const GridWs& ws, bool same, int refine) {
   const unsigned sets = same ? 1u : 2u;  // points only / points and queries
-  const dim3 gp((unsigned)ceil_div(same ? a.P2 : (a.P2 > a.P1 ? a.P2 : a.P1), kPartTile), (unsigned)a.N, sets);
-#define PO_PART(SCT, QRY)                                                                                        \
-  hipLaunchKernelGGL((grid_partition_kernel<D, SCT, QRY>), gp, dim3(kPartBlock), 0, a.stream, a.p2, a.P2, a.p1,  \
-                     a.P1, a.K, ws, a.idxs, a.dists)
+  const int64_t pmax = same ? a.P2 : (a.P2 > a.P1 ? a.P2 : a.P1);
+#define PO_PART(SCT, QRY)                                                                                         \
+  hipLaunchKernelGGL((grid_partition_kernel<D, SCT, QRY>),                                                        \
+                     dim3((unsigned)ceil_div(pmax, kPartBlock * (SCT ? kScatterPerThread : kCountPerThread)),     \
+                          (unsigned)a.N, sets),                                                                   \
+                     dim3(kPartBlock), 0, a.stream, a.p2, a.P2, a.p1, a.P1, a.K, ws, a.idxs, a.dists)
   if (same) {
     PO_PART(false, false);
     PO_PART(true, false);
@@ -823,8 +862,8 @@ static void build_d(const KnnArgs& a, const GridWs& ws, bool same, int refine) {
   }
 #undef PO_PART
   // sort workgroups per (cloud, set): enough of them to fill the chip when the batch is small
-  // (a cloud of P entries has at most P / kCoarsePoints + 1 bins)
-  const int64_t bins = (same ? a.P2 : (a.P2 > a.P1 ? a.P2 : a.P1)) / kCoarsePoints + 2;
+  // (a cloud of P entries has at most P / kCoarsePoints + cells / kFineMax + 2 bins)
+  const int64_t bins = (same ? a.P2 : (a.P2 > a.P1 ? a.P2 : a.P1)) / kCoarsePoints + ws.cell_cap / kFineMax + 2;
   int64_t wgs = 8192 / (a.N * (int64_t)sets);
   wgs = wgs < 16 ? 16 : (wgs > kCoarseMax ? kCoarseMax : wgs);
   wgs = wgs > bins ? bins : wgs;
