@@ -71,7 +71,8 @@ struct GridWs {
   int* fb2_list;      // N * P1
   int* fb3_count;     // N          queries the radius-2 quad search could not certify (expanding search)
   int* fb3_list;      // N * P1
-  unsigned* bbox;     // N * 8: ordered-uint keys of min x,y,z (atomicMin) and max x,y,z (atomicMax)
+  unsigned* bbox;     // N * 8: ordered-uint keys of min x,y,z and max x,y,z
+  float* bbox_part;   // N * ceil(P2 / 2048) * 6: min / max of every 2048-point tile
   int* grid_flag;     // N          1 = the cloud was searched through its grid (ball query: scan only the list)
   // refined cells and the box search (grid_refine.hip, knn_grid_box.h)
   int* refine_ref;    // N * cell_cap   per cell: index of its RefinedCell, or -1

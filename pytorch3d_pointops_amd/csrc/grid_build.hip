@@ -1,6 +1,6 @@
 // grid_build.hip -- build passes of the exact cell-grid searches (gfx950); see knn_grid.hip for the
 // algorithm.  All clouds of the batch in every launch, no host synchronisation:
-//   0 grid_bbox      bounding box of every p2 cloud (ordered-uint atomicMin/Max);
+//   0 grid_bbox      bounding box of every p2 cloud (one min / max slot per workgroup, reduced by grid_setup);
 //   1 grid_setup     per cloud: cubic cell size h for ~c_target points per cell, G = cells per dimension,
 //                    and per-dimension EDGE TABLES E_d[c] = min{ x in [lo,hi] : cell_d(x) >= c }, found by
 //                    bisection over the ordered fp32 bit patterns of the (monotone) cell function itself --
@@ -42,24 +42,20 @@ __device__ float edge_bisect(int c, float lo, float hi, float inv_h, int G) {
 // ---------------------------------------------------------------------------
 // pass 1: per-cloud grid parameters + edge tables
 // ---------------------------------------------------------------------------
-// pass 0: bounding boxes, all CUs.  fp32 min/max through order-preserving uint keys and
-// atomicMin / atomicMax (keys pre-set by grid_bbox_init_kernel).
+// pass 0: bounding boxes, all CUs: every workgroup reduces its 2048 points and leaves min / max in its own slot
+// (no atomics, nothing to initialise); grid_setup reduces the cloud's slots.
 constexpr int kBboxBlock = 256;
 constexpr int kBboxPerThread = 8;  // 2048 points per workgroup: enough workgroups to cover the latency of a 25 MB read
-
-__global__ void grid_bbox_init_kernel(unsigned* __restrict__ bbox, int N) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N * 8) bbox[i] = ((i & 7) < 3) ? 0xffffffffu : 0u;  // [0..2] running min, [3..5] running max
-}
+constexpr int kBboxTile = kBboxBlock * kBboxPerThread;
 
 __global__ __launch_bounds__(kBboxBlock) void grid_bbox_kernel(const float* __restrict__ p2,
                                                              const int64_t* __restrict__ lengths2, int P2, int D,
-                                                             unsigned* __restrict__ bbox) {
+                                                             float* __restrict__ bbox_part) {
   const int n = blockIdx.y;
   int len2 = (int)lengths2[n];
   len2 = len2 < 0 ? 0 : (len2 > P2 ? P2 : len2);
-  const int j0 = blockIdx.x * (kBboxBlock * kBboxPerThread);
-  if (j0 >= len2) return;
+  const int j0 = blockIdx.x * kBboxTile;
+  if (j0 >= len2) return;  // (grid_setup reads the slots of the first ceil(len2 / tile) workgroups only)
   float mn[3], mx[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
@@ -89,7 +85,6 @@ __global__ __launch_bounds__(kBboxBlock) void grid_bbox_kernel(const float* __re
       mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, kWave));
     }
   }
-  // one atomic per workgroup and bound (the 6 keys of a cloud are hot addresses)
   __shared__ float s_mn[kBboxBlock / kWave][3], s_mx[kBboxBlock / kWave][3];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   if (lane == 0) {
@@ -100,7 +95,7 @@ __global__ __launch_bounds__(kBboxBlock) void grid_bbox_kernel(const float* __re
     }
   }
   __syncthreads();
-  if (threadIdx.x < 3 && (int)threadIdx.x < D) {
+  if (threadIdx.x < 3) {
     const int d = threadIdx.x;
     float a = s_mn[0][d], b = s_mx[0][d];
 #pragma unroll
@@ -108,15 +103,16 @@ __global__ __launch_bounds__(kBboxBlock) void grid_bbox_kernel(const float* __re
       a = fminf(a, s_mn[w][d]);
       b = fmaxf(b, s_mx[w][d]);
     }
-    atomicMin(bbox + n * 8 + d, fkey(a));
-    atomicMax(bbox + n * 8 + 3 + d, fkey(b));
+    float* __restrict__ slot = bbox_part + ((int64_t)n * gridDim.x + blockIdx.x) * 6;
+    slot[d] = a;      // (+inf / -inf in dimensions >= D: grid_setup ignores them)
+    slot[3 + d] = b;
   }
 }
 
 __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     const float* __restrict__ p2, const int64_t* __restrict__ lengths1,
     const int64_t* __restrict__ lengths2, int P1, int P2, int D, float c_target, float h_min,
-    float ball_radius, int ball_K, float ball_factor, int same, GridWs ws) {
+    float ball_radius, int ball_K, float ball_factor, int same, int bbox_slots, GridWs ws) {
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
   int len2 = (int)lengths2[n];
@@ -125,6 +121,31 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
   len1 = len1 < 0 ? 0 : (len1 > P1 ? P1 : len1);
   __shared__ GridCloud s_g;
   __shared__ float s_hi[3];
+  __shared__ float s_box[kSetupBlock / kWave][6];
+  {  // bounding box of the cloud: min / max over the slots of grid_bbox_kernel
+    const int slots = (len2 + kBboxTile - 1) / kBboxTile;
+    float v[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = k < 3 ? __builtin_inff() : -__builtin_inff();
+    for (int t = tid; t < slots; t += kSetupBlock) {
+      const float* __restrict__ slot = ws.bbox_part + ((int64_t)n * bbox_slots + t) * 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v[k] = k < 3 ? fminf(v[k], slot[k]) : fmaxf(v[k], slot[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+      for (int off = kWave / 2; off > 0; off >>= 1) {
+        const float u = __shfl_xor(v[k], off, kWave);
+        v[k] = k < 3 ? fminf(v[k], u) : fmaxf(v[k], u);
+      }
+    }
+    if ((tid & (kWave - 1)) == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s_box[tid / kWave][k] = v[k];
+    }
+    __syncthreads();
+  }
   if (tid == 0) {
     GridCloud g;
     float lo[3], hi[3], e[3];
@@ -132,9 +153,15 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     for (int d = 0; d < 3; ++d) {
       float a = 0.0f, b = 0.0f;
       if (d < D && len2 > 0) {
-        a = funkey(ws.bbox[n * 8 + d]);
-        b = funkey(ws.bbox[n * 8 + 3 + d]);
+        a = s_box[0][d];
+        b = s_box[0][3 + d];
+        for (int w = 1; w < kSetupBlock / kWave; ++w) {
+          a = fminf(a, s_box[w][d]);
+          b = fmaxf(b, s_box[w][3 + d]);
+        }
       }
+      ws.bbox[n * 8 + d] = fkey(a);  // (ball query: the coarse query order of the scan-mode clouds reads these)
+      ws.bbox[n * 8 + 3 + d] = fkey(b);
       if (d >= D) a = b = 0.0f;  // padded dimensions
       lo[d] = a;
       hi[d] = b;
@@ -258,9 +285,9 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
 
 
 // Chunk prefix of the lane searches: the unit of work is one CHUNK of 64 consecutive entries of a cloud's
-// cell-sorted query order; chunk_prefix[n] = chunks of the clouds before cloud n.
-__global__ void grid_prefix_kernel(GridWs ws, int N) {  // one wave
-  const int lane = threadIdx.x;
+// cell-sorted query order; chunk_prefix[n] = chunks of the clouds before cloud n.  One wave (of the count launch).
+__device__ void grid_chunk_prefix(const GridWs& ws, int N) {
+  const int lane = threadIdx.x & (kWave - 1);
   int acc = 0;
   if (lane == 0) ws.chunk_prefix[0] = 0;
   for (int n0 = 0; n0 < N; n0 += kWave) {
@@ -356,6 +383,8 @@ __global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float*
   int* __restrict__ gstart = ws.coarse_start + coarse_row(n, set);    // per bin
   int* __restrict__ gbinof = ws.bin_of + coarse_row(n, set);          // micro-bin -> bin
   int* __restrict__ gfirst = ws.bin_first + coarse_row(n, set);       // bin -> its first micro-bin
+  if (!SCATTER && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid < kWave)
+    grid_chunk_prefix(ws, (int)gridDim.y);  // (one wave of the whole launch)
   const int i0 = blockIdx.x * kPartTile + tid;
   if (blockIdx.x * kPartTile >= P) return;
 
@@ -826,6 +855,7 @@ size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, flo
   w.fb3_count = (int*)take(sizeof(int) * (size_t)N);
   w.fb3_list = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
   w.bbox = (unsigned*)take(sizeof(unsigned) * (size_t)N * 8);
+  w.bbox_part = (float*)take(sizeof(float) * (size_t)N * 6 * (size_t)((P2 + 2047) / 2048));
   w.grid_flag = (int*)take(sizeof(int) * (size_t)N);
   w.qtmp = (float4*)take(sizeof(float4) * (size_t)N * (size_t)P1);
   w.rdesc_cap = (int)(P2 / 64 + 1);  // a refined cell holds more than refine_threshold() >= 64 points
@@ -872,13 +902,12 @@ static void build_d(const KnnArgs& a, const GridWs& ws, bool same, int refine) {
 }
 
 int grid_build(const KnnArgs& a, const GridWs& ws, const GridBuild& b) {
-  hipLaunchKernelGGL(grid_bbox_init_kernel, dim3((unsigned)ceil_div(a.N * 8, 256)), dim3(256), 0, a.stream, ws.bbox,
-                     (int)a.N);
-  hipLaunchKernelGGL(grid_bbox_kernel, dim3((unsigned)ceil_div(a.P2, kBboxBlock * kBboxPerThread), (unsigned)a.N),
-                     dim3(kBboxBlock), 0, a.stream, a.p2, a.l2, a.P2, a.D, ws.bbox);
+  const int bbox_slots = (int)ceil_div(a.P2, kBboxTile);
+  hipLaunchKernelGGL(grid_bbox_kernel, dim3((unsigned)bbox_slots, (unsigned)a.N), dim3(kBboxBlock), 0, a.stream, a.p2,
+                     a.l2, a.P2, a.D, ws.bbox_part);
   hipLaunchKernelGGL(grid_setup_kernel, dim3((unsigned)a.N), dim3(kSetupBlock), 0, a.stream, a.p2, a.l1, a.l2, a.P1,
-                     a.P2, a.D, b.c_target, b.h_min, b.ball_radius, b.ball_K, b.ball_factor, b.same ? 1 : 0, ws);
-  hipLaunchKernelGGL(grid_prefix_kernel, dim3(1), dim3(64), 0, a.stream, ws, (int)a.N);
+                     a.P2, a.D, b.c_target, b.h_min, b.ball_radius, b.ball_K, b.ball_factor, b.same ? 1 : 0, bbox_slots,
+                     ws);
   switch (a.D) {
     case 1: build_d<1>(a, ws, b.same, b.refine); break;
     case 2: build_d<2>(a, ws, b.same, b.refine); break;
