@@ -26,6 +26,25 @@ def full_lengths(n: int, p: int, device) -> torch.Tensor:
     return t
 
 
+_MAX_CACHE = {}
+
+
+def lengths_max(lengths: torch.Tensor) -> int:
+    """`int(lengths.max())`, remembered per tensor OBJECT and version counter: reading it back is a device-to-host
+    copy that stalls the launch queue, and training loops validate the same lengths tensors call after call.  (Keyed
+    by id() with a weak reference, so an entry dies with its tensor; an in-place write bumps `_version`.)"""
+    import weakref
+    key = id(lengths)
+    hit = _MAX_CACHE.get(key)
+    if hit is not None and hit[0]() is lengths and hit[1] == lengths._version:
+        return hit[2]
+    value = int(lengths.max()) if lengths.numel() else 0
+    if len(_MAX_CACHE) > 256:
+        _MAX_CACHE.clear()
+    _MAX_CACHE[key] = (weakref.ref(lengths), lengths._version, value)
+    return value
+
+
 def point_pair(p1: torch.Tensor, p2: torch.Tensor, lengths1: Optional[torch.Tensor],
                lengths2: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """Validated, contiguous (p1, p2, lengths1, lengths2) of a query / reference pair of padded clouds."""

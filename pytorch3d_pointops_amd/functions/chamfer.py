@@ -19,7 +19,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
-from ._common import alert_not_deterministic
+from ._common import alert_not_deterministic, lengths_max
 from .knn import knn_gather, knn_points
 
 
@@ -74,7 +74,7 @@ def _handle_pointcloud_input(points, lengths, features):
     else:
         if lengths.ndim != 1 or lengths.shape[0] != n:
             raise ValueError("Expected lengths to be of shape (N,)")
-        if lengths.max() > p:
+        if (lengths.max() if torch.compiler.is_compiling() else lengths_max(lengths)) > p:
             raise ValueError("A length value was too long")
     if features is not None:
         _feature_dims_ok(features)

@@ -20,5 +20,7 @@ cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 if [ "$2" != "quick" ]; then
   python tools/bench_ops.py > $OUT/ops.jsonl 2> /dev/null
   python tools/bench_knn_shapes.py > $OUT/knn_shapes.jsonl 2> /dev/null
+  python tools/bench_distributions.py > $OUT/distributions.jsonl 2> /dev/null
+  python tools/bench_long_lists.py > $OUT/long_lists.jsonl 2> /dev/null
 fi
 head -c 1500 $OUT/bench.json; echo; head -12 $OUT/kernel_stats.csv | cut -c1-100,240-330
