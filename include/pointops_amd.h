@@ -74,9 +74,11 @@ int pointops_knn_grid_fallback_counts(const void* workspace, int64_t N, int64_t 
                                       int64_t K, int32_t* counts, void* stream);
 
 /*
- * Diagnostics, same contract: stats (N,10) int32 on the device = cells per dimension G[0..2], cell count,
+ * Diagnostics, same contract: stats (N,14) int32 on the device = cells per dimension G[0..2], cell count,
  * 1 if the cloud was searched through a grid, queries uncertified after the lane pass / after the quad and box passes /
- * sent to the whole-cloud scan, queries deferred to the box search, refined cells.  (No reference counterpart; used by tools/ and the distribution benchmarks.)
+ * sent to the whole-cloud scan, queries deferred to the box search, refined cells, bins of the point sort / of the
+ * query sort, crowded bins of the point sort / of the query sort.  (No reference counterpart; used by tools/ and the
+ * distribution benchmarks.)
  */
 int pointops_knn_grid_stats(const void* workspace, int64_t N, int64_t P1, int64_t P2, int64_t K,
                             int32_t* stats, void* stream);

@@ -190,9 +190,10 @@ def knn_grid_fallback_counts(p1, p2, lengths1, lengths2, norm: int, K: int):
 
 
 def knn_grid_stats(p1, p2, lengths1, lengths2, norm: int, K: int):
-    """Diagnostics: run the grid family and return (idx, dists, stats (N, 10) int32): cells per dimension (3),
+    """Diagnostics: run the grid family and return (idx, dists, stats (N, 14) int32): cells per dimension (3),
     cell count, grid used, queries uncertified after the lane pass / the quad + box passes / sent to the whole-cloud
-    scan, queries deferred to the box search, refined cells."""
+    scan, queries deferred to the box search, refined cells, bins of the point / query sort, crowded bins of the
+    point / query sort."""
     dev = _require_gpu(p1, p2, lengths1, lengths2)
     p1 = p1.contiguous()
     p2 = p1 if p2 is p1 else p2.contiguous()
@@ -205,7 +206,7 @@ def knn_grid_stats(p1, p2, lengths1, lengths2, norm: int, K: int):
         dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
         ws_bytes = _lib.pointops_knn_workspace_bytes(N, P1, P2, D, K, 3)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        stats = torch.zeros((N, 10), dtype=torch.int32, device=dev)
+        stats = torch.zeros((N, 14), dtype=torch.int32, device=dev)
         _check(_lib.pointops_knn_points_idx(p1.data_ptr(), p2.data_ptr(), lengths1.data_ptr(),
                                             lengths2.data_ptr(), N, P1, P2, D, int(norm), int(K), 3,
                                             idxs.data_ptr(), dists.data_ptr(), ws.data_ptr(), ws_bytes,

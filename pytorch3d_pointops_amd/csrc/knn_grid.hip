@@ -109,14 +109,15 @@ extern "C" int pointops_knn_grid_fallback_counts(const void* workspace, int64_t 
 }
 
 // grid geometry + fallback counters of the last knn_points_idx call that used `workspace`:
-// stats (N, 10) int32 = G[0], G[1], G[2], ncell, use_grid, uncertified after the lane pass, after the quad + box passes,
-// sent to the whole-cloud scan, deferred to the box search, refined cells
+// stats (N, 14) int32 = G[0], G[1], G[2], ncell, use_grid, uncertified after the lane pass, after the quad + box passes,
+// sent to the whole-cloud scan, deferred to the box search, refined cells; build: bins of the point sort / of the query
+// sort, crowded bins (listed ones) of the point sort / of the query sort
 namespace pointops {
 __global__ void grid_stats_kernel(GridWs ws, int N, int32_t* __restrict__ stats) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const GridCloud g = ws.cloud[n];
-  int32_t* s = stats + (int64_t)n * 10;
+  int32_t* s = stats + (int64_t)n * 14;
   s[0] = g.G[0];
   s[1] = g.G[1];
   s[2] = g.G[2];
@@ -127,6 +128,10 @@ __global__ void grid_stats_kernel(GridWs ws, int N, int32_t* __restrict__ stats)
   s[7] = ws.fb2_count[n];
   s[8] = ws.box_count[n];
   s[9] = ws.rcount[n];
+  s[10] = ws.nbins[n * 2];
+  s[11] = g.same ? 0 : ws.nbins[n * 2 + 1];
+  s[12] = ws.crowded_count[n * 2];
+  s[13] = g.same ? 0 : ws.crowded_count[n * 2 + 1];
 }
 }  // namespace pointops
 

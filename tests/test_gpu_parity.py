@@ -1141,3 +1141,40 @@ def test_knn_refined_cells_and_box_search(dev, oracle, monkeypatch, K, norm):
     monkeypatch.delenv("POINTOPS_DEBUG")
     i2, d2 = _C.knn_points_idx(*args, 2 if K <= 32 else 0)
     assert torch.equal(i2, idx) and torch.equal(d2, d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [3, 2])
+def test_knn_grid_many_crowded_bins(dev, D):
+    """The two-level sort of the grid build (grid_build.hip) on a cloud with MORE crowded bins than it lists (100 tight
+    clusters of 9 000 points: every cluster is a bin of its own, 64 of them are placed by slices with the per-cell ranks
+    of the scatter launch, the rest by one workgroup each), as points and as queries (self-query included): sampled
+    queries against a brute-force torch distance row over the whole cloud, nearest neighbours with ties to the lowest
+    index, bit-equal distances."""
+    from pytorch3d_pointops_amd.functions import knn_points
+
+    rng = np.random.default_rng(2701)
+    centres = rng.random((100, D), dtype=np.float32)
+    pts = (centres[:, None, :] + rng.random((100, 9000, D), dtype=np.float32) * np.float32(2e-4)).reshape(-1, D)
+    pts = np.concatenate([pts, rng.random((50000, D), dtype=np.float32)])
+    rng.shuffle(pts)
+    p2 = G(pts[None], dev)
+    q = np.concatenate([pts[::37][:20000] + np.float32(1e-5), rng.random((10000, D), dtype=np.float32),
+                        centres[:1] + rng.random((10000, D), dtype=np.float32) * np.float32(2e-4)])  # a crowded query bin
+    p1 = G(q[None].astype(np.float32), dev)
+    K = 4
+    from pytorch3d_pointops_amd import _C
+    full_len = lambda t: torch.full((1,), t.shape[1], dtype=torch.int64, device=dev)  # noqa: E731
+    st = _C.knn_grid_stats(p1, p2, full_len(p1), full_len(p2), 2, K)[2].cpu().numpy()[0]
+    assert st[4] == 1 and st[10] >= 100 and st[12] == 64 and st[13] >= 1, st  # > 64 crowded bins: the list is full
+    for a in (p1, p2):  # p1 != p2, and the self-query (the point sort is the query order)
+        r = knn_points(a, p2, K=K, version=3)
+        qs = torch.arange(5, a.shape[1], max(1, a.shape[1] // 300), device=dev)
+        dq = a[0, qs][:, None, :] - p2[0][None, :, :]
+        dq = dq * dq
+        full = dq[..., 0] + dq[..., 1]
+        if D == 3:
+            full = full + dq[..., 2]
+        order = torch.argsort(full, dim=1, stable=True)[:, :K]
+        assert torch.equal(r.idx[0, qs], order), D
+        assert torch.equal(r.dists[0, qs], torch.gather(full, 1, order)), D
