@@ -186,13 +186,15 @@ __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const un
   }
 }
 
+// (second launch bound = waves per SIMD the compiler has to leave room for: the 64-slot list needs 261 registers
+// without it, five more than two waves allow)
 template <int D, int KC, int NORM>
-__global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
+__global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kernel(
     const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const int* __restrict__ chunk_prefix,
     const float* __restrict__ edges, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
     const float4* __restrict__ qsorted, int* __restrict__ fb_count, int* __restrict__ fb_list,
     unsigned* __restrict__ fb_kth, int* __restrict__ box_count, int* __restrict__ box_list, int defer_limit,
-    int cell_cap, int P1, int P2, int K, int N, int64_t* __restrict__ idxs, float* __restrict__ dists) {
+    int uncertified_to_box, int cell_cap, int P1, int P2, int K, int N, int64_t* __restrict__ idxs, float* __restrict__ dists) {
   using Cfg = LaneCfg<KC>;
   constexpr bool kUseQueue = Cfg::kUseQueue;
   constexpr int kQueueCap = Cfg::kQueueCap;
@@ -290,7 +292,10 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_lane_kernel(
       if (ok) {
         const int64_t row = (int64_t)n * P1 + qi;
         write_row_f64<KC>(top, K, g.len2, idxs + row * K, dists + row * K);
-      } else if (overlong) {
+      } else if (overlong || uncertified_to_box) {
+        // (long lists have no quad pass: on big clouds their uncertified queries take the box search -- one lane per
+        // query, a box sized from the local density -- instead of the wave-per-query search: 1.5 ms of the 5.1 ms at
+        // K=64, cfg2 size; small clouds send too few of them to fill the box kernel: 0.33 vs 0.69 ms at 4 x 16384)
         const int pos = atomicAdd(box_count + n, 1);
         box_list[(int64_t)n * P1 + pos] = qi;
       } else {
@@ -690,7 +695,7 @@ static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
                      (const GridCloud*)ws.cloud, (const int*)ws.chunk_prefix, (const float*)ws.edges,
                      (const int*)ws.cell_start, (const float4*)ws.sorted, (const float4*)ws.qsorted, ws.fb_count,
                      ws.fb_list, ws.fb_kth, ws.box_count, ws.box_list, kDeferFactor * refine_threshold(ws.c_target),
-                     ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
+                     (KC > 32 && a.P1 >= 32768) ? 1 : 0, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
   if constexpr (KC <= 32) if (quad) {
     int64_t wx = a.P1 / (32 * kQuadQueries);  // a few % of a cloud arrive here
     wx = wx < 8 ? 8 : wx > 4096 ? 4096 : wx;
