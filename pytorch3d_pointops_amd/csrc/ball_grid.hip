@@ -337,7 +337,9 @@ int ball_grid_run(const KnnArgs& a, float radius, void* workspace, const int** f
   b.refine = -1;
   const int rc = grid_build(a, ws, b);
   if (rc != POINTOPS_OK) return rc;
-  const int wgs = 256 * 32;
+  int64_t chunks = (int64_t)a.N * ceil_div(a.P1, kGridWave);  // one chunk of 64 queries per workgroup (see knn_grid_search.h)
+  chunks = (chunks + 7) / 8 * 8;
+  const int wgs = (int)(chunks < 2048 ? 2048 : (chunks > (1 << 20) ? (1 << 20) : chunks));
   const float radius2 = radius * radius;  // fp32 product (ball_query_cpu.cpp:26)
   switch (a.D) {
     case 1: ball_run_d<1>(a, radius2, ws, wgs); break;

@@ -2,6 +2,7 @@
 // exactness argument and the pass list are in knn_grid.hip.  Templates only: the translation units
 // knn_grid_d*.hip instantiate them per point dimension so that they compile in parallel.
 #pragma once
+#include "debug.h"
 #include "grid.h"
 #include "knn_common.h"
 #include "sort_net.h"
@@ -690,7 +691,12 @@ static void launch_grid_box(const KnnArgs& a, const GridWs& ws, bool quad);  // 
 
 template <int D, int KC, int NORM>
 static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
-  const int wgs = 256 * 32;  // one wave64 per workgroup, up to 32 waves per CU resident
+  // One wave64 per workgroup and ONE chunk of 64 queries per workgroup where the launch allows it (a multiple of 8: the
+  // XCD-aware order): the hardware's workgroup dispatcher then balances the chunks (cfg2, ms per step: 3 840 resident
+  // workgroups looping over their share 0.870, 8 192 0.757, 32 768 = one per chunk 0.731).
+  int64_t chunks = (int64_t)a.N * ceil_div(a.P1, kGridWave);
+  chunks = (chunks + 7) / 8 * 8;
+  const int wgs = (int)debug_knob("lane_wgs", (long)(chunks < 2048 ? 2048 : (chunks > (1 << 20) ? (1 << 20) : chunks)));
   hipLaunchKernelGGL((knn_grid_lane_kernel<D, KC, NORM>), dim3((unsigned)wgs), dim3(kGridWave), 0, a.stream, a.p1,
                      (const GridCloud*)ws.cloud, (const int*)ws.chunk_prefix, (const float*)ws.edges,
                      (const int*)ws.cell_start, (const float4*)ws.sorted, (const float4*)ws.qsorted, ws.fb_count,
