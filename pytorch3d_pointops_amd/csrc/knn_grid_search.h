@@ -323,7 +323,8 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
 // <= 7 contiguous runs (per-lane 16-byte gathers, eight in flight per pipeline stage, stale-threshold
 // queue, sorting-network merges), and two quad-permute exchange steps merge the four sorted lists,
 // after which every lane of the quad holds the cube's KC best.  (Kernel time at cfg2 with 4 / 8 / 16
-// lanes per query: 83 / 96 / 97-107 us -- the pass is throughput-bound, not bound by one wave's chain,
+// lanes per query: 83 / 96 / 97-107 us in round 1, 63 / 67 / 69 us with this round's kernel (mirror DPP steps for
+// the wider merges) -- the pass is throughput-bound, not bound by one wave's chain,
 // so fewer, longer lanes win.)  The cube grows from 3x3x3 only past the faces that an ESTIMATE of the
 // KC-th distance reaches.  The same rigorous face bound decides; what is still uncertified (far-away
 // queries) goes to the expanding wave search.
