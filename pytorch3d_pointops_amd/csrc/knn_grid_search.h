@@ -541,6 +541,8 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
 // ---------------------------------------------------------------------------
 constexpr int kWaveKernelBlock = 256;
 constexpr int kWaveKernelWgsPerCloud = 256;  // x 4 waves: the pass is latency-bound per query, so one query per wave
+// (Waves own a fixed stride of the list.  Drawing the next query from a per-cloud counter was measured and dropped:
+// 1 024 waves per cloud on one address -- 17 -> 243 us on the slab cloud, whose 10 000 queries here are cheap.)
                                              // wherever a cloud sends it up to ~1000 (64: 2.1 -> ms at 761 queries per cloud)
 constexpr int kWaveRegionCap = 1 << 22;  // records: in effect the wave search always finishes (a cube that holds an
                                          // over-full cell is still 64 lanes on one coalesced stream; the whole-cloud
