@@ -320,7 +320,7 @@ def main():
             "traffic": float(tj["traffic_bytes_per_step"]) if tj else None,
             "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
                               if tj else None,
-            "kernel": "knn_points_idx = grid build (bbox, histogram, scan, counting sort) + knn_grid_lane_kernel "
+            "kernel": "knn_points_idx = grid build (bbox, two-level counting sort: count / scatter / per-bin sort) + knn_grid_lane_kernel "
                       "(dominant) + exact fallbacks; `achieved` prices the WHOLE op, HIP-event timed on the launch stream",
             "algorithmic_bytes_per_launch": algo_bytes,
             "avg_launch_ms": avg_kern_s * 1e3,

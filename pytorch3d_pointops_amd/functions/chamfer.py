@@ -145,6 +145,64 @@ class _chamfer_direction(Function):
         return (gx, gy, None, None, None, None, None, None, *gxf, *gyf)
 
 
+class _chamfer_pair(Function):
+    """BOTH directions, their sum and the batch reduction as one autograd node (no weights, point_reduction in
+    {"sum","mean"}): the composed form spends ~20 launches on (1+F, N)-sized tensors per call -- selects, adds, sums,
+    divisions and their backward twins -- which cost as much as a K=1 search at the cfg4 size.  Returns 1+F tensors
+    (loss, then one per feature), each () after a batch reduction or (N,) without one."""
+
+    @staticmethod
+    def forward(ctx, x, y, x_lengths, y_lengths, norm, mean, abs_cosine, batch_reduction, *feats):
+        F_ = len(feats) // 2
+        x_feats = [f.contiguous() for f in feats[:F_]]
+        y_feats = [f.contiguous() for f in feats[F_:]]
+        x, y = x.contiguous(), y.contiguous()
+        N = x.shape[0]
+
+        def direction(a, b, a_len, b_len, a_feats, b_feats):
+            idx, dists = _C.knn_points_idx(a, b, a_len, b_len, norm, 1, -1)
+            idx = idx.view(idx.shape[0], idx.shape[1])
+            return idx, _C.chamfer_forward(dists.view(idx.shape), idx, a_len, b_len, None, a_feats, b_feats,
+                                           abs_cosine, mean)
+
+        idx_xy, rows = direction(x, y, x_lengths, y_lengths, x_feats, y_feats)
+        idx_yx, rows_yx = direction(y, x, y_lengths, x_lengths, y_feats, x_feats)
+        rows += rows_yx  # (1+F, N)
+        if batch_reduction is not None:
+            rows = rows.sum(1)
+            if batch_reduction == "mean":
+                rows /= max(N, 1)
+        ctx.save_for_backward(x, y, idx_xy, idx_yx, x_lengths, y_lengths, *x_feats, *y_feats)
+        ctx.cfg = (int(norm), bool(mean), bool(abs_cosine), batch_reduction, F_)
+        return tuple(r.clone() for r in rows.unbind(0))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        norm, mean, abs_cosine, batch_reduction, F_ = ctx.cfg
+        x, y, idx_xy, idx_yx, xl, yl = ctx.saved_tensors[:6]
+        x_feats = list(ctx.saved_tensors[6:6 + F_])
+        y_feats = list(ctx.saved_tensors[6 + F_:6 + 2 * F_])
+        N = x.shape[0]
+        like = next(g for g in grads if g is not None)
+        g = torch.stack([torch.zeros_like(like) if gi is None else gi for gi in grads]).float()
+        if batch_reduction is not None:  # (1+F,) -> the same value for every cloud
+            if batch_reduction == "mean":
+                g = g / max(N, 1)
+            g = g[:, None].expand(1 + F_, N)
+        g = g.contiguous()
+        alert_not_deterministic("chamfer_distance backward")  # grad of the TARGET cloud: fp32 atomics
+        gx, gy, gxf, gyf = _C.chamfer_backward(x, y, idx_xy, xl, yl, None, g, norm, x_feats, y_feats, abs_cosine,
+                                               mean)
+        gy2, gx2, gyf2, gxf2 = _C.chamfer_backward(y, x, idx_yx, yl, xl, None, g, norm, y_feats, x_feats, abs_cosine,
+                                                   mean)
+        gx.add_(gx2)
+        gy.add_(gy2)
+        for a, b in zip(list(gxf) + list(gyf), list(gxf2) + list(gyf2)):
+            a.add_(b)
+        return (gx, gy, None, None, None, None, None, None, *gxf, *gyf)
+
+
 def _fused_direction_ok(x, y, x_features, y_features, feature_names, return_features, point_reduction):
     if point_reduction not in ("sum", "mean") or torch.compiler.is_compiling():
         return False  # (traced graphs take the composed path over the registered ops)
@@ -192,21 +250,26 @@ def _direction_composed(x, y, x_lengths, y_lengths, x_features, y_features, name
     return _Terms(done[""], {k: done[k] for k in names} if names else None)
 
 
-def _chamfer_distance_single_direction(x, y, x_lengths, y_lengths, x_features, y_features, weights,
-                                       point_reduction: Union[str, None], norm: int, abs_cosine: bool,
-                                       feature_names: Union[list, None] = None):
-    """(point term, feature terms or None) of the direction x -> y (reference: functions/chamfer.py:85-189)."""
+def _direction_names(x, y, x_features, y_features, feature_names) -> list:
+    """The feature names a direction x -> y evaluates, after the reference's argument checks
+    (functions/chamfer.py:100-118): every requested name present on both sides, batch and point dimension equal."""
     have_both = x_features is not None and y_features is not None
     if feature_names and have_both:
         for name in feature_names:
             for side, table in (("x_features", x_features), ("y_features", y_features)):
                 if name not in table:
                     raise ValueError(f"Feature '{name}' is missing in {side}.")
-    names = list(feature_names) if (have_both and feature_names) else []
-
-    N, P1, D = x.shape
-    if y.shape[0] != N or y.shape[2] != D:
+    if y.shape[0] != x.shape[0] or y.shape[2] != x.shape[2]:
         raise ValueError("y does not have the correct shape.")
+    return list(feature_names) if (have_both and feature_names) else []
+
+
+def _chamfer_distance_single_direction(x, y, x_lengths, y_lengths, x_features, y_features, weights,
+                                       point_reduction: Union[str, None], norm: int, abs_cosine: bool,
+                                       feature_names: Union[list, None] = None):
+    """(point term, feature terms or None) of the direction x -> y (reference: functions/chamfer.py:85-189)."""
+    names = _direction_names(x, y, x_features, y_features, feature_names)
+    N, P1, D = x.shape
     if weights is not None:
         if weights.size(0) != N:
             raise ValueError("weights must be of shape (N,).")
@@ -302,6 +365,16 @@ def chamfer_distance(
 
     x, x_lengths, x_features = _handle_pointcloud_input(x, x_lengths, x_features)
     y, y_lengths, y_features = _handle_pointcloud_input(y, y_lengths, y_features)
+
+    if not single_directional and weights is None and torch.is_tensor(x) and torch.is_tensor(y):
+        names = _direction_names(x, y, x_features, y_features, feature_names)
+        if (names == _direction_names(y, x, y_features, x_features, feature_names)
+                and _fused_direction_ok(x, y, x_features, y_features, names, bool(names), point_reduction)
+                and _fused_direction_ok(y, x, y_features, x_features, names, bool(names), point_reduction)):
+            flat = [x_features[k] for k in names] + [y_features[k] for k in names]
+            outs = _chamfer_pair.apply(x, y, x_lengths, y_lengths, norm, point_reduction == "mean", abs_cosine,
+                                       batch_reduction, *flat)
+            return outs[0], ({k: outs[1 + i] for i, k in enumerate(names)} if names else None)
 
     def direction(a, b, a_len, b_len, a_feat, b_feat):
         return _chamfer_distance_single_direction(a, b, a_len, b_len, a_feat, b_feat, weights, point_reduction, norm,
