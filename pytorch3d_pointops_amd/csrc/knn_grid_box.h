@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_box_kernel(
     const float* __restrict__ p1, GridWs ws, int P1, int P2, int K, int* __restrict__ out_count,
     int* __restrict__ out_list, int64_t* __restrict__ idxs, float* __restrict__ dists) {
   constexpr bool kUseQueue = LaneCfg<KC>::kUseQueue;
-  constexpr int kQueueCap = LaneCfg<KC>::kQueueCap;
+  constexpr int kQueueCap = LaneCfg<KC>::kQueueLds;
   __shared__ double s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
   __shared__ unsigned s_rows[kBoxRows + 1][kGridWave];
   const int n = blockIdx.y;

@@ -56,7 +56,10 @@ constexpr int kLaneRows = 9;
 template <int KC>
 struct LaneCfg {
   static constexpr bool kUseQueue = KC >= 8;
-  static constexpr int kQueueCap = 16;                  // per-lane LDS queue slots (KC = 8 merges the 8 smallest)
+  static constexpr int kQueueCap = 16;                  // keys a flush sorts (KC = 8 merges the 8 smallest)
+  // per-lane LDS queue slots: 15 of them + the 2.5 KB run table = 10 KB per wave, SIXTEEN waves per CU (the VGPR limit of
+  // the K <= 16 kernels) instead of fifteen: cfg2 0.715 -> 0.703 ms per step (14 slots: 0.707)
+  static constexpr int kQueueLds = KC <= 16 ? 15 : 16;
 #ifndef POINTOPS_LANE_GROUP
 #define POINTOPS_LANE_GROUP 4  // 8 measured 0.776 vs 0.755 ms at cfg2 (K=16), 1.46 vs 1.31 ms at K=32: fewer masked slots
 #endif                         // (a run of ~19 records wastes 1.5 of 4 against 3.5 of 8) beat the fewer, wider groups
@@ -82,6 +85,7 @@ __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const un
   using Cfg = LaneCfg<KC>;
   constexpr bool kUseQueue = Cfg::kUseQueue;
   constexpr int kQueueCap = Cfg::kQueueCap;
+  constexpr int kQueueLds = Cfg::kQueueLds;
   constexpr int kSub = Cfg::kSub;
   constexpr int G = Cfg::kGroup;
   constexpr int kGroupBytes = G * 16;
@@ -161,14 +165,14 @@ __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const un
         part(std::integral_constant<int, 0>{});
         crem = rem;
         more = __any(crem > 0);
-        full = __any(qn > lane + (kQueueCap - kSub) * kGridWave);
+        full = __any(qn > lane + (kQueueLds - kSub) * kGridWave);
       } while (!full && more);
       // merge: queue -> sorted network -> list
       double qk[kQueueCap];
 #pragma unroll
-      for (int t = 0; t < kQueueCap; ++t) qk[t] = qbase[t * kGridWave];  // free slots hold the empty key
+      for (int t = 0; t < kQueueCap; ++t) qk[t] = t < kQueueLds ? qbase[t * kGridWave] : TopKF64<KC>::empty();
 #pragma unroll
-      for (int t = 0; t < kQueueCap; ++t) qbase[t * kGridWave] = TopKF64<KC>::empty();
+      for (int t = 0; t < kQueueLds; ++t) qbase[t * kGridWave] = TopKF64<KC>::empty();  // (free slots hold the empty key)
       bitonic_sort<kQueueCap>(qk);
       constexpr int kMeet = KC < kQueueCap ? KC : kQueueCap;
 #pragma unroll
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
     int uncertified_to_box, int cell_cap, int P1, int P2, int K, int N, int64_t* __restrict__ idxs, float* __restrict__ dists) {
   using Cfg = LaneCfg<KC>;
   constexpr bool kUseQueue = Cfg::kUseQueue;
-  constexpr int kQueueCap = Cfg::kQueueCap;
+  constexpr int kQueueCap = Cfg::kQueueLds;
   constexpr int kSub = Cfg::kSub;
   constexpr int G = Cfg::kGroup;
   static_assert(G % kSub == 0 && G <= kSortedPad, "group geometry");
