@@ -141,3 +141,21 @@ def test_chamfer_validation_errors():
         chamfer_distance(x, x, x_lengths=torch.tensor([5, 6]))
     with pytest.raises(ValueError, match="should be either"):
         chamfer_distance([1, 2], x)
+
+
+def test_lengths_validation_cache_follows_the_tensor():
+    """`lengths_max` remembers `int(lengths.max())` per tensor object and version counter (the validation of the
+    reference's chamfer API, functions/chamfer.py:69-70, without a device-to-host copy per call): an in-place write is
+    seen, a new tensor is a new entry, and the error text is the reference's."""
+    from pytorch3d_pointops_amd.functions._common import lengths_max
+    from pytorch3d_pointops_amd.functions.chamfer import _handle_pointcloud_input
+
+    x = torch.rand(2, 5, 3)
+    lengths = torch.tensor([5, 4])
+    assert lengths_max(lengths) == 5 and lengths_max(lengths) == 5
+    _handle_pointcloud_input(x, lengths, None)
+    lengths[1] = 6  # in-place: the version counter moves, the remembered value is dropped
+    assert lengths_max(lengths) == 6
+    with pytest.raises(ValueError, match="too long"):
+        _handle_pointcloud_input(x, lengths, None)
+    assert lengths_max(torch.tensor([1, 2])) == 2 and lengths_max(torch.zeros(0, dtype=torch.int64)) == 0
