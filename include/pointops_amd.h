@@ -199,6 +199,19 @@ int pointops_chamfer_backward(const float* x, const float* y, const int64_t* idx
                               const float* const* x_feats, const float* const* y_feats, const int64_t* C,
                               int abs_cosine, int mean, float* grad_x, float* grad_y,
                               float* const* grad_x_feats, float* const* grad_y_feats, void* stream);
+/*
+ * The same gradients ADDED to buffers that already hold gradients (no reference counterpart: the reference sums the
+ * two directions of a bidirectional chamfer distance through autograd).  After pointops_chamfer_backward for the
+ * direction x -> y, the direction y -> x calls this with the roles swapped -- (x, y) := (y, x), grad_x := the first
+ * call's grad_y, grad_y := its grad_x, likewise the feature gradients: the dense query-side terms are added element
+ * by element, the target-side terms by the same fp32 atomics, nothing is zero-filled.
+ */
+int pointops_chamfer_backward_accumulate(const float* x, const float* y, const int64_t* idx,
+                                         const int64_t* x_lengths, const int64_t* y_lengths, const float* weights,
+                                         const float* grad_out, int64_t N, int64_t P1, int64_t P2, int64_t D,
+                                         int norm, int F, const float* const* x_feats, const float* const* y_feats,
+                                         const int64_t* C, int abs_cosine, int mean, float* grad_x, float* grad_y,
+                                         float* const* grad_x_feats, float* const* grad_y_feats, void* stream);
 
 /*
  * Inverse-CDF sampling -- replaces `_C.sample_pdf` (reference: csrc/sample_pdf/sample_pdf.h:58-78,

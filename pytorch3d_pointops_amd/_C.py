@@ -57,6 +57,8 @@ _SIGNATURES = {
                                         _int, _vp, _vp, _sz, _vp]),
     "pointops_chamfer_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int,
                                          _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "pointops_chamfer_backward_accumulate": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int,
+                                                    _int, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -491,8 +493,10 @@ def chamfer_forward(dists, idx, x_lengths, y_lengths, weights, x_feats, y_feats,
 
 
 def chamfer_backward(x, y, idx, x_lengths, y_lengths, weights, grad_out, norm: int, x_feats, y_feats,
-                     abs_cosine: bool, mean: bool):
-    """Closed-form gradients of chamfer_forward's outputs: returns (grad_x, grad_y, [grad_x_feat], [grad_y_feat])."""
+                     abs_cosine: bool, mean: bool, into=None):
+    """Closed-form gradients of chamfer_forward's outputs: returns (grad_x, grad_y, [grad_x_feat], [grad_y_feat]).
+    `into` = (grad_x, grad_y, [grad_x_feat], [grad_y_feat]) buffers that already hold gradients (the other direction's,
+    roles swapped): the gradients are ADDED to them (pointops_chamfer_backward_accumulate) and they are returned."""
     opt = [weights] if weights is not None else []
     dev = _require_gpu(x, y, idx, grad_out, x_lengths, y_lengths, *opt, *x_feats, *y_feats)
     x, y, grad_out = _f32c(x, "x"), _f32c(y, "y"), _f32c(grad_out, "grad_out")
@@ -509,18 +513,25 @@ def chamfer_backward(x, y, idx, x_lengths, y_lengths, weights, grad_out, norm: i
     _check_chamfer_shapes(N, P1, P2, idx, x_lengths, y_lengths, weights, x_feats, y_feats)
     C = (ctypes.c_int64 * max(F, 1))(*[int(t.shape[2]) for t in x_feats])
     with torch.cuda.device(dev):
-        grad_x = torch.empty_like(x)
-        grad_y = torch.empty_like(y)
-        gxf = [torch.empty_like(t) for t in x_feats]
-        gyf = [torch.empty_like(t) for t in y_feats]
+        if into is None:
+            grad_x = torch.empty_like(x)
+            grad_y = torch.empty_like(y)
+            gxf = [torch.empty_like(t) for t in x_feats]
+            gyf = [torch.empty_like(t) for t in y_feats]
+            entry = _lib.pointops_chamfer_backward
+        else:
+            grad_x, grad_y, gxf, gyf = into
+            gxf, gyf = list(gxf), list(gyf)
+            for g, like in zip([grad_x, grad_y, *gxf, *gyf], [x, y, *x_feats, *y_feats]):
+                if (g.shape != like.shape or g.dtype != torch.float32 or not g.is_contiguous()
+                        or g.device != like.device):
+                    raise RuntimeError("chamfer_backward: `into` buffers must match the inputs (fp32, contiguous)")
+            entry = _lib.pointops_chamfer_backward_accumulate
         _check(
-            _lib.pointops_chamfer_backward(x.data_ptr(), y.data_ptr(), idx.data_ptr(), x_lengths.data_ptr(),
-                                           y_lengths.data_ptr(),
-                                           weights.data_ptr() if weights is not None else None,
-                                           grad_out.data_ptr(), N, P1, P2, D, int(norm), F, _ptr_array(x_feats),
-                                           _ptr_array(y_feats), C, int(bool(abs_cosine)), int(bool(mean)),
-                                           grad_x.data_ptr(), grad_y.data_ptr(), _ptr_array(gxf), _ptr_array(gyf),
-                                           _stream()),
+            entry(x.data_ptr(), y.data_ptr(), idx.data_ptr(), x_lengths.data_ptr(), y_lengths.data_ptr(),
+                  weights.data_ptr() if weights is not None else None, grad_out.data_ptr(), N, P1, P2, D, int(norm),
+                  F, _ptr_array(x_feats), _ptr_array(y_feats), C, int(bool(abs_cosine)), int(bool(mean)),
+                  grad_x.data_ptr(), grad_y.data_ptr(), _ptr_array(gxf), _ptr_array(gyf), _stream()),
             "chamfer_backward",
         )
     return grad_x, grad_y, gxf, gyf

@@ -183,12 +183,16 @@ __global__ __launch_bounds__(kWave) void chamfer_finalize_kernel(const float* __
   }
 }
 
+// dense gradient of the query side: stored, or -- accumulating call (pointops_chamfer_backward_accumulate) -- added to
+// what the other direction left there (the element has ONE owner thread per launch, launches are stream-ordered)
+__device__ __forceinline__ void cf_put(float* __restrict__ p, float v, int acc) { *p = acc ? *p + v : v; }
+
 template <int NORM>
 __global__ __launch_bounds__(kCfBlock) void chamfer_backward_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const int64_t* __restrict__ idx,
     const int64_t* __restrict__ x_lengths, const int64_t* __restrict__ y_lengths,
     const float* __restrict__ weights, const float* __restrict__ grad_out, int N, int64_t P1, int64_t P2, int D,
-    ChamferFeat ft, int abs_cosine, int mean, float* __restrict__ grad_x, float* __restrict__ grad_y) {
+    ChamferFeat ft, int abs_cosine, int mean, int acc, float* __restrict__ grad_x, float* __restrict__ grad_y) {
   const int n = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * kCfBlock + threadIdx.x;
   if (i >= P1) return;
@@ -196,7 +200,8 @@ __global__ __launch_bounds__(kCfBlock) void chamfer_backward_kernel(
   if (len > P1) len = P1;
   const int64_t row = (int64_t)n * P1 + i;
   const bool y_valid = y_lengths[n] > 0;
-  if (i >= len) {  // masked rows: zero gradients
+  if (i >= len) {  // masked rows: zero gradients (accumulating: nothing to add)
+    if (acc) return;
     for (int d = 0; d < D; ++d) grad_x[row * D + d] = 0.0f;
 #pragma unroll
     for (int f = 0; f < kCfMaxFeat; ++f)
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(kCfBlock) void chamfer_backward_kernel(
       else diff = 2.0f * a * (xv - yv);
       if (diff != 0.0f) atomicAdd(grad_y + yrow * D + d, -1.0f * diff);
     }
-    grad_x[row * D + d] = diff;
+    cf_put(grad_x + row * D + d, diff, acc);
   }
   // feature terms: d/d(features) of 1 - |cos| (or 1 - cos)
 #pragma unroll
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(kCfBlock) void chamfer_backward_kernel(
       if (c < C) {
         // dcos/dx1 = (x2n - cos * x1n) / |x1| when |x1| > eps, x2n / eps otherwise (clamped norm)
         const float gx = b * ix * (nx > eps ? (yn[c] - cosv * xn[c]) : yn[c]);
-        ft.gx[f][row * C + c] = gx;
+        cf_put(ft.gx[f] + row * C + c, gx, acc);
         if (y_valid) {
           const float gy = b * iy * (ny > eps ? (xn[c] - cosv * yn[c]) : xn[c]);
           if (gy != 0.0f) atomicAdd(ft.gy[f] + yrow * C + c, gy);
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(kCfBlock) void chamfer_backward4_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const int64_t* __restrict__ idx,
     const int64_t* __restrict__ x_lengths, const int64_t* __restrict__ y_lengths,
     const float* __restrict__ weights, const float* __restrict__ grad_out, int N, int64_t P1, int64_t P2, int D,
-    ChamferFeat ft, int abs_cosine, int mean, float* __restrict__ grad_x, float* __restrict__ grad_y) {
+    ChamferFeat ft, int abs_cosine, int mean, int acc, float* __restrict__ grad_x, float* __restrict__ grad_y) {
   const int n = blockIdx.y;
   const int64_t t = (int64_t)blockIdx.x * kCfBlock + threadIdx.x;
   const int64_t i = t >> 2;
@@ -274,6 +279,7 @@ __global__ __launch_bounds__(kCfBlock) void chamfer_backward4_kernel(
   const int64_t row = (int64_t)n * P1 + i;
   const bool y_valid = y_lengths[n] > 0;
   if (i >= len) {
+    if (acc) return;
     if (c < D) grad_x[row * D + c] = 0.0f;
 #pragma unroll
     for (int f = 0; f < kCfMaxFeat; ++f)
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(kCfBlock) void chamfer_backward4_kernel(
       else diff = 2.0f * a * (xv - yv);
       if (diff != 0.0f) atomicAdd(grad_y + yrow * D + c, -1.0f * diff);
     }
-    grad_x[row * D + c] = diff;
+    cf_put(grad_x + row * D + c, diff, acc);
   }
 #pragma unroll
   for (int f = 0; f < kCfMaxFeat; ++f) {
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(kCfBlock) void chamfer_backward4_kernel(
         xc = (k == c) ? xv[k] : xc;
         yc = (k == c) ? yv[k] : yc;
       }
-      ft.gx[f][row * C + c] = b * ix * (nx > eps ? (yc - cosv * xc) : yc);
+      cf_put(ft.gx[f] + row * C + c, b * ix * (nx > eps ? (yc - cosv * xc) : yc), acc);
       if (y_valid) {
         const float gy = b * iy * (ny > eps ? (xc - cosv * yc) : xc);
         if (gy != 0.0f) atomicAdd(ft.gy[f] + yrow * C + c, gy);
@@ -384,12 +390,12 @@ extern "C" int pointops_chamfer_forward(const float* dists, const int64_t* idx, 
   return check_launch("chamfer_forward");
 }
 
-extern "C" int pointops_chamfer_backward(const float* x, const float* y, const int64_t* idx,
-                                         const int64_t* x_lengths, const int64_t* y_lengths, const float* weights,
-                                         const float* grad_out, int64_t N, int64_t P1, int64_t P2, int64_t D,
-                                         int norm, int F, const float* const* x_feats, const float* const* y_feats,
-                                         const int64_t* C, int abs_cosine, int mean, float* grad_x, float* grad_y,
-                                         float* const* grad_x_feats, float* const* grad_y_feats, void* stream_) {
+static int chamfer_backward_impl(const float* x, const float* y, const int64_t* idx, const int64_t* x_lengths,
+                                 const int64_t* y_lengths, const float* weights, const float* grad_out, int64_t N,
+                                 int64_t P1, int64_t P2, int64_t D, int norm, int F, const float* const* x_feats,
+                                 const float* const* y_feats, const int64_t* C, int abs_cosine, int mean,
+                                 float* grad_x, float* grad_y, float* const* grad_x_feats,
+                                 float* const* grad_y_feats, void* stream_, int acc) {
   using namespace pointops;
   POINTOPS_REQUIRE(norm == 1 || norm == 2, "chamfer_backward: norm must be 1 or 2");
   POINTOPS_REQUIRE(N >= 0 && P1 >= 0 && P2 >= 0 && D >= 1 && N < 65536, "chamfer_backward: bad sizes");
@@ -397,10 +403,10 @@ extern "C" int pointops_chamfer_backward(const float* x, const float* y, const i
   const int rc = cf_fill(&ft, F, x_feats, y_feats, grad_x_feats, grad_y_feats, C);
   if (rc != POINTOPS_OK) return rc;
   hipStream_t stream = (hipStream_t)stream_;
-  if (N * P2 * D > 0 && hipMemsetAsync(grad_y, 0, sizeof(float) * (size_t)(N * P2 * D), stream) != hipSuccess)
+  if (!acc && N * P2 * D > 0 && hipMemsetAsync(grad_y, 0, sizeof(float) * (size_t)(N * P2 * D), stream) != hipSuccess)
     return check_launch("chamfer_backward(memset)");
   for (int f = 0; f < F; ++f)
-    if (N * P2 * C[f] > 0 &&
+    if (!acc && N * P2 * C[f] > 0 &&
         hipMemsetAsync(grad_y_feats[f], 0, sizeof(float) * (size_t)(N * P2 * C[f]), stream) != hipSuccess)
       return check_launch("chamfer_backward(memset)");
   if (N == 0 || P1 == 0) return POINTOPS_OK;
@@ -410,18 +416,40 @@ extern "C" int pointops_chamfer_backward(const float* x, const float* y, const i
     const dim3 grid4((unsigned)ceil_div(P1 * 4, kCfBlock), (unsigned)N), block4(kCfBlock);
     if (norm == 1)
       hipLaunchKernelGGL(chamfer_backward4_kernel<1>, grid4, block4, 0, stream, x, y, idx, x_lengths, y_lengths,
-                         weights, grad_out, (int)N, P1, P2, (int)D, ft, abs_cosine, mean, grad_x, grad_y);
+                         weights, grad_out, (int)N, P1, P2, (int)D, ft, abs_cosine, mean, acc, grad_x, grad_y);
     else
       hipLaunchKernelGGL(chamfer_backward4_kernel<2>, grid4, block4, 0, stream, x, y, idx, x_lengths, y_lengths,
-                         weights, grad_out, (int)N, P1, P2, (int)D, ft, abs_cosine, mean, grad_x, grad_y);
+                         weights, grad_out, (int)N, P1, P2, (int)D, ft, abs_cosine, mean, acc, grad_x, grad_y);
     return check_launch("chamfer_backward");
   }
   const dim3 grid((unsigned)ceil_div(P1, kCfBlock), (unsigned)N), block(kCfBlock);
   if (norm == 1)
     hipLaunchKernelGGL(chamfer_backward_kernel<1>, grid, block, 0, stream, x, y, idx, x_lengths, y_lengths, weights,
-                       grad_out, (int)N, P1, P2, (int)D, ft, abs_cosine, mean, grad_x, grad_y);
+                       grad_out, (int)N, P1, P2, (int)D, ft, abs_cosine, mean, acc, grad_x, grad_y);
   else
     hipLaunchKernelGGL(chamfer_backward_kernel<2>, grid, block, 0, stream, x, y, idx, x_lengths, y_lengths, weights,
-                       grad_out, (int)N, P1, P2, (int)D, ft, abs_cosine, mean, grad_x, grad_y);
+                       grad_out, (int)N, P1, P2, (int)D, ft, abs_cosine, mean, acc, grad_x, grad_y);
   return check_launch("chamfer_backward");
+}
+
+extern "C" int pointops_chamfer_backward(const float* x, const float* y, const int64_t* idx,
+                                         const int64_t* x_lengths, const int64_t* y_lengths, const float* weights,
+                                         const float* grad_out, int64_t N, int64_t P1, int64_t P2, int64_t D,
+                                         int norm, int F, const float* const* x_feats, const float* const* y_feats,
+                                         const int64_t* C, int abs_cosine, int mean, float* grad_x, float* grad_y,
+                                         float* const* grad_x_feats, float* const* grad_y_feats, void* stream) {
+  return chamfer_backward_impl(x, y, idx, x_lengths, y_lengths, weights, grad_out, N, P1, P2, D, norm, F, x_feats,
+                               y_feats, C, abs_cosine, mean, grad_x, grad_y, grad_x_feats, grad_y_feats, stream, 0);
+}
+
+extern "C" int pointops_chamfer_backward_accumulate(const float* x, const float* y, const int64_t* idx,
+                                                    const int64_t* x_lengths, const int64_t* y_lengths,
+                                                    const float* weights, const float* grad_out, int64_t N,
+                                                    int64_t P1, int64_t P2, int64_t D, int norm, int F,
+                                                    const float* const* x_feats, const float* const* y_feats,
+                                                    const int64_t* C, int abs_cosine, int mean, float* grad_x,
+                                                    float* grad_y, float* const* grad_x_feats,
+                                                    float* const* grad_y_feats, void* stream) {
+  return chamfer_backward_impl(x, y, idx, x_lengths, y_lengths, weights, grad_out, N, P1, P2, D, norm, F, x_feats,
+                               y_feats, C, abs_cosine, mean, grad_x, grad_y, grad_x_feats, grad_y_feats, stream, 1);
 }

@@ -194,12 +194,10 @@ class _chamfer_pair(Function):
         alert_not_deterministic("chamfer_distance backward")  # grad of the TARGET cloud: fp32 atomics
         gx, gy, gxf, gyf = _C.chamfer_backward(x, y, idx_xy, xl, yl, None, g, norm, x_feats, y_feats, abs_cosine,
                                                mean)
-        gy2, gx2, gyf2, gxf2 = _C.chamfer_backward(y, x, idx_yx, yl, xl, None, g, norm, y_feats, x_feats, abs_cosine,
-                                                   mean)
-        gx.add_(gx2)
-        gy.add_(gy2)
-        for a, b in zip(list(gxf) + list(gyf), list(gxf2) + list(gyf2)):
-            a.add_(b)
+        # the reverse direction ADDS into the same buffers (its dense terms into gy, its atomics into gx): no second
+        # set of gradients, no zero fills, no sums of (N, P, D) tensors
+        _C.chamfer_backward(y, x, idx_yx, yl, xl, None, g, norm, y_feats, x_feats, abs_cosine, mean,
+                            into=(gy, gx, gyf, gxf))
         return (gx, gy, None, None, None, None, None, None, *gxf, *gyf)
 
 
