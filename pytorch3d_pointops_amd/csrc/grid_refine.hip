@@ -21,6 +21,25 @@ constexpr int kRefineBlock = 1024;
 constexpr int kRefineWgs = 8;  // workgroups per cloud walking the cloud's list of refined cells (each claims 128 KB
                                // of LDS: 256 of them are one round of the chip, and an empty list costs one round)
 
+// fn(record, i) for the `count` records behind `src`, the workgroup's threads striding over them with FOUR loads in
+// flight each (a cell of 75 000 points is 73 strides of one workgroup: one load at a time made every pass ~50 us)
+template <typename Fn>
+__device__ __forceinline__ void for_each4(const float4* __restrict__ src, int count, Fn fn) {
+  for (int i0 = threadIdx.x; i0 < count; i0 += 4 * kRefineBlock) {
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = i0 + u * kRefineBlock;
+      if (j < count) p[u] = src[j];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = i0 + u * kRefineBlock;
+      if (j < count) fn(p[u], j);
+    }
+  }
+}
+
 template <int D>
 __global__ __launch_bounds__(kRefineBlock) void grid_refine_build_kernel(GridWs ws, int P2) {
   extern __shared__ int s_hist[];  // s^3 counters of the cell being built
@@ -40,15 +59,14 @@ __global__ __launch_bounds__(kRefineBlock) void grid_refine_build_kernel(GridWs 
     const int nsub = s * s * s;
     // 1. mean and sigma of the cell's points (fp64 sums: exactness is not needed, robustness is)
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < count; i += kRefineBlock) {
-      const float4 p = rec[start + i];
+    for_each4(rec + start, count, [&](const float4 p, int) {
       const double v[3] = {p.x, p.y, p.z};
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         acc[d] += v[d];
         acc[3 + d] += v[d] * v[d];
       }
-    }
+    });
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
 #pragma unroll
@@ -96,7 +114,7 @@ __global__ __launch_bounds__(kRefineBlock) void grid_refine_build_kernel(GridWs 
       return (iz * s + iy) * s + ix;
     };
     // 2. histogram
-    for (int i = tid; i < count; i += kRefineBlock) atomicAdd(&s_hist[sub_index(rec[start + i])], 1);
+    for_each4(rec + start, count, [&](const float4 p, int) { atomicAdd(&s_hist[sub_index(p)], 1); });
     __syncthreads();
     // 3. exclusive scan of nsub counters (each thread a contiguous slice) -> table in the pool, cursors in LDS
     int* __restrict__ table = ws.pool + (int64_t)n * ws.pool_cap + dp->pool_off;
@@ -123,19 +141,18 @@ __global__ __launch_bounds__(kRefineBlock) void grid_refine_build_kernel(GridWs 
     if (tid == kRefineBlock - 1) table[nsub] = count;
     __syncthreads();
     // 4. scatter into the scratch copy, then back into the cell's range
-    for (int i = tid; i < count; i += kRefineBlock) {
-      const float4 p = rec[start + i];
-      tmp[start + atomicAdd(&s_hist[sub_index(p)], 1)] = p;
-    }
+    for_each4(rec + start, count, [&](const float4 p, int) { tmp[start + atomicAdd(&s_hist[sub_index(p)], 1)] = p; });
     __threadfence_block();
     __syncthreads();
-    for (int i = tid; i < count; i += kRefineBlock) rec[start + i] = tmp[start + i];
+    for_each4(tmp + start, count, [&](const float4 p, int i) { rec[start + i] = p; });
   }
 }
 
 int grid_refine(const KnnArgs& a, const GridWs& ws) {
   const size_t lds = sizeof(int) * (size_t)kRefineMaxS * kRefineMaxS * kRefineMaxS;  // 128 KB: one workgroup per CU
-  const dim3 grid(kRefineWgs, (unsigned)a.N);
+  // (a workgroup claims 128 KB of LDS = one CU: up to 256 of them chip-wide, at least kRefineWgs per cloud)
+  const int64_t per_cloud = 256 / (a.N > 0 ? a.N : 1);
+  const dim3 grid((unsigned)(per_cloud < kRefineWgs ? kRefineWgs : (per_cloud > 64 ? 64 : per_cloud)), (unsigned)a.N);
 #define PO_REFINE(DD)                                                                                            \
   {                                                                                                              \
     static bool attr = false;                                                                                    \
