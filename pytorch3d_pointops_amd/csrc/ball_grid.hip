@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kGridWave) void ball_grid_lane_kernel(
   for (int j = blockIdx.x / kNumXcd; j < per_xcd; j += gridDim.x / kNumXcd) {
     const int item = xcd * per_xcd + j;
     if (item >= total) break;
-    const int n = item_cloud(chunk_prefix, N, item);
+    const int n = item_cloud(chunk_prefix, N, item, (P1 + kGridWave - 1) / kGridWave);
     const GridCloud g = clouds[n];
     const int c0 = (item - chunk_prefix[n]) * kGridWave;
     const bool active = c0 + lane < g.len1;

@@ -216,8 +216,12 @@ __device__ __forceinline__ unsigned seed_threshold(float lb, bool whole) {
   return whole ? 0x7f800000u : (b > 0u ? b - 1u : 0u);
 }
 
-// cloud of a chunk item: largest n with prefix[n] <= item (wave-uniform binary search)
-__device__ __forceinline__ int item_cloud(const int* __restrict__ prefix, int N, int item) {
+// cloud of a chunk item: largest n with prefix[n] <= item (wave-uniform).  `per_cloud` = chunks of a FULL cloud: in a
+// batch of full clouds item / per_cloud is the answer, checked with two independent loads; ragged batches fall back to the
+// binary search (log2 N dependent loads at the head of every workgroup).
+__device__ __forceinline__ int item_cloud(const int* __restrict__ prefix, int N, int item, int per_cloud) {
+  const int guess = min(item / per_cloud, N - 1);
+  if (prefix[guess] <= item && item < prefix[guess + 1]) return guess;
   int lo_n = 0, hi_n = N;
   while (hi_n - lo_n > 1) {
     const int mid = (lo_n + hi_n) >> 1;

@@ -2,7 +2,6 @@
 // exactness argument and the pass list are in knn_grid.hip.  Templates only: the translation units
 // knn_grid_d*.hip instantiate them per point dimension so that they compile in parallel.
 #pragma once
-#include "debug.h"
 #include "grid.h"
 #include "knn_common.h"
 #include "sort_net.h"
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
   for (int j = blockIdx.x / kNumXcd; j < per_xcd; j += gridDim.x / kNumXcd) {
     const int item = xcd * per_xcd + j;
     if (item >= total) break;
-    const int n = item_cloud(chunk_prefix, N, item);
+    const int n = item_cloud(chunk_prefix, N, item, (P1 + kGridWave - 1) / kGridWave);
     const GridCloud g = clouds[n];
     const int c0 = (item - chunk_prefix[n]) * kGridWave;
     const bool active = c0 + lane < g.len1;
@@ -703,7 +702,7 @@ static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
   // workgroups looping over their share 0.870, 8 192 0.757, 32 768 = one per chunk 0.731).
   int64_t chunks = (int64_t)a.N * ceil_div(a.P1, kGridWave);
   chunks = (chunks + 7) / 8 * 8;
-  const int wgs = (int)debug_knob("lane_wgs", (long)(chunks < 2048 ? 2048 : (chunks > (1 << 20) ? (1 << 20) : chunks)));
+  const int wgs = (int)(chunks < 2048 ? 2048 : (chunks > (1 << 20) ? (1 << 20) : chunks));
   hipLaunchKernelGGL((knn_grid_lane_kernel<D, KC, NORM>), dim3((unsigned)wgs), dim3(kGridWave), 0, a.stream, a.p1,
                      (const GridCloud*)ws.cloud, (const int*)ws.chunk_prefix, (const float*)ws.edges,
                      (const int*)ws.cell_start, (const float4*)ws.sorted, (const float4*)ws.qsorted, ws.fb_count,
