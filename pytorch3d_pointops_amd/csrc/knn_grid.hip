@@ -11,12 +11,15 @@
 //
 //
 // Passes (all clouds of the batch in every launch, no host synchronisation):
-//   0-4 grid_build.hip: bounding boxes, cell size + exact edge tables, counting sorts of the points into
-//       (x,y,z,idx) float4 records by cell and of the query ids by cell;
+//   0-4 grid_build.hip: bounding boxes, cell size + exact edge tables, two-level counting sort of the points and of
+//       the queries into (x,y,z,idx) float4 records by cell (count / scatter by bin / per-bin sort);
+//   4b  grid_refine.hip: sub-grids of over-full cells (multi-scale clouds);
 //   5   knn_grid_lane_kernel (knn_grid_search.h): one query per lane over the 3x3x3 cell cube around its
 //       cell; afterwards each lane checks kth_dist < LB, LB = the bound below over the cube's faces; on
 //       failure the query id goes to the fallback list;
 //   5b  knn_grid_quad_kernel: four lanes per uncertified query, cube grown where an estimate says so;
+//   5c  knn_grid_box_kernel (knn_grid_box.h): box search over refined cells for over-full neighbourhoods (and for
+//       the uncertified queries of the 64-slot lists, which have no quad pass);
 //   6   knn_grid_wave_kernel: wave-per-query search of a cell cube that doubles until certified;
 //   7   knn_reg_kernel (knn.hip): whole-cloud scan for the queries pass 6 gave up on and for clouds
 //       without a usable grid.
