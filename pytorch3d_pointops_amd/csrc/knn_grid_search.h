@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
 constexpr int kQuadLanes = 4;  // lanes per query
 constexpr int kQuadRows = (25 + kQuadLanes - 1) / kQuadLanes;
 constexpr int kQuadQueries = kGridWave / kQuadLanes;
-constexpr int kQuadFetch = 8;  // gathers in flight per lane and pipeline stage
+constexpr int kQuadFetch = 8;  // gathers in flight per lane and pipeline stage (4: 76 us, 16: 104 us instead of 65 us)
 constexpr int kQuadMaxRecords = 1024;  // per lane of the quad
 __device__ constexpr signed char kQuadDy[32] = {0, 0, 0, -1, 1, -1, -1, 1, 1, 0, 0, -2, 2, -1, 1, -1, 1, -2, -2, 2, 2, -2, -2, 2, 2, 0, 0, 0, 0, 0, 0, 0};
 __device__ constexpr signed char kQuadDz[32] = {0, -1, 1, 0, 0, -1, 1, -1, 1, -2, 2, 0, 0, -2, -2, 2, 2, -1, 1, -1, 1, -2, 2, -2, 2, 0, 0, 0, 0, 0, 0, 0};
