@@ -214,6 +214,10 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
     float inv_h = 1.0f;
     int G[3] = {1, 1, 1};
     if (ok && any_active) {
+      // at most kGMax cells per dimension: a long 1-D cloud would otherwise clamp nearly all of its points into the
+      // last cell (exact, but one cell = the whole cloud)
+      for (int d = 0; d < 3; ++d)
+        if (active[d]) h = fmaxf(h, e[d] * (1.0f / ((float)kGMax - 0.5f)));
       for (int it = 0; it < 64; ++it) {
         inv_h = 1.0f / h;
         if (!(inv_h > 0.0f && inv_h <= FLT_MAX)) {
