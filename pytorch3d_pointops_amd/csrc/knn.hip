@@ -218,7 +218,8 @@ int knn_split_count(int64_t N, int64_t P1, int64_t P2, int64_t K) {
   if (waves >= 2048 || P2 < 512) return 1;
   int64_t s = ceil_div(4096, waves);
   s = std::min<int64_t>(s, 8);
-  s = std::min<int64_t>(s, P2 / 256);  // a slice keeps >= 256 candidates
+  s = std::min<int64_t>(s, P2 / 128);  // a slice keeps >= 128 candidates (cfg1, B=2 N=M=1024 K=8, us per call by (max
+                                       // slices, candidates): (8, 256) 48.6, (8, 128) 37.5, (16, 64) 41.4, (32, 32) 56.0)
   return (int)std::max<int64_t>(s, 1);
 }
 
