@@ -287,13 +287,12 @@ static int choose_version(int version, int64_t N, int64_t P1, int64_t P2, int64_
   const bool grid_ok = pointops_knn_check_version(3, D, K) && P2 <= (1LL << 20) && N < 65536;
   if (version == 3 && !grid_ok) version = -1;
   if (version >= 0 && version <= 3 && pointops_knn_check_version(version, D, K)) return version;
-  // auto: the grid only pays once the all-pairs scan is long enough to amortise its ~15 launches
-  // (sort + scan passes, ~0.15-0.3 ms); below that the sliced brute-force scan is faster.  The
-  // crossover in total pairs grows as K shrinks, because short lists make the scan cheap per pair
-  // (measured v2 against v3, N = 1..32 clouds of 4096..32768 points, profiles/r01_knn_crossover.txt).
+  // auto: the grid only pays once the all-pairs scan is longer than the grid's floor of ~12 launches (0.08-0.1 ms);
+  // below that the sliced brute-force scan is faster.  The crossover in total pairs grows as K shrinks, because short
+  // lists make the scan cheap per pair (measured v2 against v3, N = 1..32 clouds of 4096..32768 points:
+  // profiles/r02_knn_crossover.txt; round 1's build passes put it at 1.5 * 2^29 / 2^28 / 2^27 for K <= 2 / 4 / 8).
   const double pairs = (double)N * (double)P1 * (double)P2;
-  const double cross = K <= 2 ? 1.5 * (double)(1LL << 29) : K <= 4 ? (double)(1LL << 28) : K <= 8 ? (double)(1LL << 27)
-                       : (double)(1LL << 24);
+  const double cross = K <= 2 ? (double)(1LL << 28) : K <= 4 ? (double)(1LL << 27) : (double)(1LL << 24);
   if (grid_ok && P2 >= 4096 && pairs >= cross) return 3;
   if (pointops_knn_check_version(2, D, K)) return 2;
   return 0;
