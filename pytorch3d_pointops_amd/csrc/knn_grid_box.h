@@ -191,7 +191,11 @@ template <int D, int KC, int NORM>
 static void launch_grid_box(const KnnArgs& a, const GridWs& ws, bool quad) {
   // one 64-query chunk of the box list per workgroup where the grid allows it: the lanes' work differs by orders of
   // magnitude on the clouds that need this pass (u^4 cloud 4.63 -> 4.10 ms, half_in_cluster 3.20 -> 2.53 ms against one
-  // workgroup per 8 chunks; the 32 768 workgroups that find an empty list on a uniform cloud cost < 10 us)
+  // workgroup per 8 chunks; the 32 768 workgroups that find an empty list on a uniform cloud cost < 10 us).  Measured and
+  // dropped, both with a pool of 256 entries per workgroup: lanes that draw a new query as soon as theirs is certified
+  // (every round then costs the longest walk of a lane on its third radius: 4.10 -> 4.82 ms) and round-by-round
+  // processing with the uncertified queries compacted into a pending list per radius (4.10 -> 5.10 ms: fewer, longer
+  // workgroups and 4 KB more LDS cost more than the idle lanes of the late radii)
   int64_t wx = a.P1 / kGridWave;
   wx = wx < 8 ? 8 : wx > 1024 ? 1024 : wx;
   hipLaunchKernelGGL((knn_grid_box_kernel<D, KC, NORM>), dim3((unsigned)wx, (unsigned)a.N), dim3(kGridWave), 0, a.stream,
