@@ -365,8 +365,10 @@ __device__ __forceinline__ void dpp_merge(TopKF64<KC>& top) {
   }
 }
 
+// (second launch bound: the 32-slot kernel needs 259 registers without it, three more than two waves per SIMD allow:
+// 186 -> 138 us at the cfg2 size)
 template <int D, int KC, int NORM>
-__global__ __launch_bounds__(kGridWave) void knn_grid_quad_kernel(
+__global__ __launch_bounds__(kGridWave, KC >= 32 ? 2 : 1) void knn_grid_quad_kernel(
     const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const float* __restrict__ edges,
     const int* __restrict__ cell_start, const float4* __restrict__ sorted, const int* __restrict__ fb_count,
     const int* __restrict__ fb_list, const unsigned* __restrict__ fb_kth, int* __restrict__ fb3_count,
