@@ -107,14 +107,20 @@ def launch_ranks(args) -> int:
 
 # ---------------------------------------------------------------------------------------------
 def kernel_source_digest():
-    """sha256 over the HIP sources: ties committed counter profiles to the code they were measured on
-    (there is no .git on the GPU box)."""
+    """sha256 over the HIP sources without comments and whitespace: ties committed counter profiles to the code they
+    were measured on (there is no .git on the GPU box)."""
     import glob
+
+    import re
 
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "pytorch3d_pointops_amd", "csrc", "*"))):
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        text = open(f, "r", errors="replace").read()
+        # the CODE: comments and whitespace do not move a counter (no string literal of the sources holds "//")
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -5,13 +5,14 @@
 //                    and per-dimension EDGE TABLES E_d[c] = min{ x in [lo,hi] : cell_d(x) >= c }, found by
 //                    bisection over the ordered fp32 bit patterns of the (monotone) cell function itself --
 //                    no error analysis of the binning arithmetic is needed;
-//   2 grid_partition<count>   entries per COARSE bin (a contiguous range of ~1000-2000 entries' worth of cells): p2 points
-//                    and p1 queries, LDS histogram per tile, one device atomic per (tile, bin); zero rows for padded
-//                    queries;
-//   3 grid_partition<scatter> (x,y,z,idx) float4 records of points and of queries, grouped by coarse bin;
-//   4 grid_sort      one workgroup per coarse bin: cells counted, scanned and sorted in LDS -> cell_start, the
+//   2 grid_partition<count>   entries per MICRO-BIN (cell id >> mshift, <= 1024 per cloud): p2 points and p1 queries,
+//                    LDS histogram per tile, one device atomic per (tile, micro-bin); the last tile groups consecutive
+//                    micro-bins into BINS of ~1000-2000 entries and lists the crowded ones; zero rows for padded queries;
+//   3 grid_partition<scatter> (x,y,z,idx) float4 records of points and of queries, grouped by bin (records of crowded
+//                    bins also get their rank inside their cell);
+//   4 grid_sort      one workgroup per bin: cells counted, scanned and sorted in LDS -> cell_start, the
 //                    point records by cell, the query records by cell (the searches read their queries
-//                    coalesced, in cell order), the refined-cell marks.
+//                    coalesced, in cell order), the refined-cell marks; crowded bins by slices.
 // When the queries ARE the points (same buffer, same lengths: self-KNN, ball query of a cloud on itself,
 // get_point_covariances) the query passes are skipped: the point sort is the query order.
 #include <stdlib.h>
@@ -21,7 +22,7 @@
 namespace pointops {
 
 constexpr int kSetupBlock = 1024;  // 3 x 1026 edge bisections per cloud
-constexpr int kCoarsePoints = 1024;  // entries a coarse bin of the two-level sort aims at
+constexpr int kCoarsePoints = 1024;  // entries a bin of the two-level sort aims at
 
 __device__ __forceinline__ int64_t coarse_row(int n, int set) { return ((int64_t)n * 2 + set) * (kCoarseMax + 1); }
 
@@ -336,9 +337,9 @@ constexpr int kCountPerThread = 16;   // count launch: tiles of 16384 entries (h
 constexpr int kScatterPerThread = 8;  // scatter launch: tiles of 8192 entries (the records stay in registers)
 constexpr int kSortBlock = 256;  // (512 / 1024 threads: 89 / 157 us instead of 62 us for the cfg2 sort pass)
 constexpr int kHashBits = 12, kHashSlots = 1 << kHashBits, kHashProbes = 8;  // partition pass: cells of crowded bins
-constexpr int kCrowded = 8192;       // records from which a coarse bin is CROWDED: sorted by slices (grid_sort_kernel)
+constexpr int kCrowded = 8192;       // records from which a bin is CROWDED: sorted by slices (grid_sort_kernel)
 constexpr int kCrowdedSlice = 4096;  // records per slice
-constexpr int kFineMax = 1 << kFineLogMax;  // cells per coarse bin cap: the LDS counters of one sort workgroup
+constexpr int kFineMax = 1 << kFineLogMax;  // cells per bin cap: the LDS counters of one sort workgroup
 static_assert(kCoarseMax == kPartBlock, "the count launch's last tile scans one micro-bin per thread");
 
 // atomicAdd(&counter[slot], 1) of every live lane of a wave; when all of them name the SAME counter (a bin whose
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float*
 // hitting one LDS bank
 __device__ __forceinline__ int fine_slot(int f) { return f + (f >> 5); }
 
-// SORT pass: workgroup (b mod gridDim.x) of (cloud, set) sorts coarse bin b by cell.  `refine` as in GridBuild.
+// SORT pass: workgroup (b mod gridDim.x) of (cloud, set) sorts bin b by cell.  `refine` as in GridBuild.
 // A CROWDED bin (more than kCrowded records: a cluster, the dense end of a density gradient) would keep one workgroup
 // busy for hundreds of microseconds; the partition pass has already counted its records per cell and handed every
 // record its rank inside its cell (fine_count / rank arrays), so its slices of kCrowdedSlice records are placed by as
