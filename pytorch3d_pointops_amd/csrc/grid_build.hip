@@ -324,7 +324,7 @@ __device__ void grid_chunk_prefix(const GridWs& ws, int N) {
 //              each non-empty one to the cloud's counters with ONE device atomic; the last tile to finish groups
 //              consecutive micro-bins into BINS of ~1000-2000 entries and <= 4096 cells (so the bins follow the data: a
 //              surface or a cluster occupies few micro-bins) and lists the crowded ones;
-//              scatter: records grouped by bin (runs of tens to hundreds of records written together);
+//              scatter: tiles of 4096 entries write their records grouped by bin (runs of tens of records);
 //   SORT       one workgroup per bin: histogram of the bin's cells in LDS, exclusive scan -> the bin's slice
 //              of cell_start (and the refined-cell bookkeeping), then the records move to their final place inside the
 //              bin's own compact range of the sorted array (second read from L2).
@@ -334,7 +334,8 @@ __device__ void grid_chunk_prefix(const GridWs& ws, int N) {
 // ---------------------------------------------------------------------------
 constexpr int kPartBlock = 1024;
 constexpr int kCountPerThread = 16;   // count launch: tiles of 16384 entries (half the device atomics of 8192)
-constexpr int kScatterPerThread = 8;  // scatter launch: tiles of 8192 entries (the records stay in registers)
+constexpr int kScatterPerThread = 4;  // scatter launch: tiles of 4096 entries, the records stay in registers (cfg2: 42.6 /
+                                      // 29.6 / 30.9 us for tiles of 8192 / 4096 / 2048; count tiles of 8192 / 32768: 22 / 31.5 us)
 constexpr int kSortBlock = 256;  // (512 / 1024 threads: 89 / 157 us instead of 62 us for the cfg2 sort pass)
 constexpr int kHashBits = 12, kHashSlots = 1 << kHashBits, kHashProbes = 8;  // partition pass: cells of crowded bins
 constexpr int kCrowded = 8192;       // records from which a bin is CROWDED: sorted by slices (grid_sort_kernel)
