@@ -22,7 +22,8 @@
 namespace pointops {
 
 constexpr int kSetupBlock = 1024;  // 3 x 1026 edge bisections per cloud
-constexpr int kCoarsePoints = 1024;  // entries a bin of the two-level sort aims at
+constexpr int kCoarsePoints = 1024;  // entries a bin of the two-level sort aims at (512 / 2048: cfg2 sort pass 48 / 46 us
+                                     // instead of 36 us)
 
 __device__ __forceinline__ int64_t coarse_row(int n, int set) { return ((int64_t)n * 2 + set) * (kCoarseMax + 1); }
 
@@ -336,7 +337,7 @@ constexpr int kPartBlock = 1024;
 constexpr int kCountPerThread = 16;   // count launch: tiles of 16384 entries (half the device atomics of 8192)
 constexpr int kScatterPerThread = 4;  // scatter launch: tiles of 4096 entries, the records stay in registers (cfg2: 42.6 /
                                       // 29.6 / 30.9 us for tiles of 8192 / 4096 / 2048; count tiles of 8192 / 32768: 22 / 31.5 us)
-constexpr int kSortBlock = 256;  // (512 / 1024 threads: 89 / 157 us instead of 62 us for the cfg2 sort pass)
+constexpr int kSortBlock = 256;  // (128 / 512 / 1024 threads: 43 / 89 / 157 us against 36 / 62 / 62 us for the cfg2 sort pass)
 constexpr int kHashBits = 12, kHashSlots = 1 << kHashBits, kHashProbes = 8;  // partition pass: cells of crowded bins
 constexpr int kCrowded = 8192;       // records from which a bin is CROWDED: sorted by slices (grid_sort_kernel)
 constexpr int kCrowdedSlice = 4096;  // records per slice
