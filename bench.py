@@ -106,8 +106,12 @@ def launch_ranks(args) -> int:
 
 
 # ---------------------------------------------------------------------------------------------
+# sources of the kernels that run in the headline step (knn_points_idx through the grid family and its fallbacks)
+KNN_PATH_SOURCES = ("capi", "common", "debug", "grid", "knn.", "knn_common", "knn_grid", "knn_wide", "sort_net")
+
+
 def kernel_source_digest():
-    """sha256 over the HIP sources without comments and whitespace: ties committed counter profiles to the code they
+    """sha256 over the HIP sources of the headline step without comments and whitespace: ties committed counter profiles to the code they
     were measured on (there is no .git on the GPU box)."""
     import glob
 
@@ -115,6 +119,8 @@ def kernel_source_digest():
 
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "pytorch3d_pointops_amd", "csrc", "*"))):
+        if not os.path.basename(f).startswith(KNN_PATH_SOURCES):
+            continue  # (the other operators' kernels do not run in the headline step)
         h.update(os.path.basename(f).encode())
         text = open(f, "r", errors="replace").read()
         # the CODE: comments and whitespace do not move a counter (no string literal of the sources holds "//")
