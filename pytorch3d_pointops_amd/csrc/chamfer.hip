@@ -70,7 +70,7 @@ extern "C" int pointops_chamfer_reduce(const float* dists, const int64_t* length
 namespace pointops {
 
 constexpr int kCfBlock = 256;
-constexpr int kCfPerThread = 4;
+constexpr int kCfPerThread = 2;  // (4 / 2 / 1 points per thread: forward + finalize 33.2 / 27.5 / 27.2 us per direction at cfg4)
 constexpr int kCfMaxFeat = 4;
 constexpr int kCfMaxC = 16;  // feature channels held in registers
 
