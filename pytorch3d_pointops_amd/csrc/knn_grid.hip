@@ -53,13 +53,14 @@ size_t knn_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K) {
   return grid_carve(nullptr, nullptr, N, P1, P2, knn_cell_target((int)K));
 }
 
-static bool grid_quad_mode(int P1) {
-  // The quad pass has a ~60 us floor (one wave walking ~200 candidates per lane), which only pays
-  // when a cloud sends it hundreds of queries: measured 1.16 vs 1.23 ms at 32 x 65536 queries, but
-  // 0.33 vs 0.24 ms at 32 x 4096, where the expanding wave search takes the uncertified queries
-  // directly.  Debug knob grid_quad=0/1 forces the choice (tests of both paths).
+static bool grid_quad_mode(int64_t queries, int kc) {
+  // The quad pass has a ~60 us floor (one wave walking ~200 candidates per lane), which only pays when the BATCH sends
+  // it thousands of queries; below that the expanding wave search takes the uncertified queries directly.  Measured
+  // with / without the pass (ms): 64 x 16384 queries K=16 0.412 / 0.461, 32 x 32768 K=8 0.303 / 0.320, but 8 x 32768
+  // K=16 0.206 / 0.186 and 64 x 8192 K=8 0.241 / 0.220; 32-slot lists: 64 x 8192 0.468 / 0.555, 16 x 16384
+  // 0.307 / 0.319, 32 x 4096 0.271 / 0.252.  Debug knob grid_quad=0/1 forces the choice (tests of both paths).
   const long k = debug_knob("grid_quad", -1);
-  return k >= 0 ? k != 0 : P1 >= 32768;
+  return k >= 0 ? k != 0 : queries >= (kc >= 32 ? (1 << 18) : (1 << 20));
 }
 
 int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
@@ -77,7 +78,7 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
   if (rc != POINTOPS_OK) return rc;
   if (b.refine && (rc = grid_refine(a, ws)) != POINTOPS_OK) return rc;
   const int kc = grid_kc(a.K);
-  const bool quad = kc <= 32 && grid_quad_mode(a.P1);  // (64-slot lists: four of them do not fit a quad's registers)
+  const bool quad = kc <= 32 && grid_quad_mode(a.N * (int64_t)a.P1, kc);  // (64-slot lists: four of them do not fit a quad's registers)
   switch (a.D) {
     case 1: grid_search_d1(a, ws, norm, kc, quad); break;
     case 2: grid_search_d2(a, ws, norm, kc, quad); break;
