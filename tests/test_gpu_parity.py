@@ -1180,3 +1180,30 @@ def test_knn_grid_many_crowded_bins(dev, D):
         order = torch.argsort(full, dim=1, stable=True)[:, :K]
         assert torch.equal(r.idx[0, qs], order), D
         assert torch.equal(r.dists[0, qs], torch.gather(full, 1, order)), D
+
+
+@pytest.mark.gpu
+def test_chamfer_backward_accumulate_equals_sum_of_directions(dev):
+    """pointops_chamfer_backward_accumulate (include/pointops_amd.h): the reverse direction's gradients ADDED into the
+    buffers the forward direction's call filled equal the sum of two separate backward calls (the reference sums the
+    directions through autograd, functions/chamfer.py:316-354) -- dense terms exactly up to one fp32 addition, the
+    atomically scattered ones within the 1e-5 of every atomic accumulation; padded rows stay zero."""
+    from pytorch3d_pointops_amd import _C
+
+    N, P1, P2 = 3, 700, 900
+    x, y = G(cases.cloud(3101, (N, P1, 3)), dev), G(cases.cloud(3102, (N, P2, 3)), dev)
+    xf = [G(cases.cloud(3103, (N, P1, 3)), dev)]
+    yf = [G(cases.cloud(3104, (N, P2, 3)), dev)]
+    xl, yl = G(np.array([700, 333, 1]), dev), G(np.array([900, 10, 450]), dev)
+    g = G(cases.cloud(3105, (2, N)), dev)
+    idx_xy = _C.knn_points_idx(x, y, xl, yl, 2, 1, -1)[0][..., 0].contiguous()
+    idx_yx = _C.knn_points_idx(y, x, yl, xl, 2, 1, -1)[0][..., 0].contiguous()
+    gx, gy, gxf, gyf = _C.chamfer_backward(x, y, idx_xy, xl, yl, None, g, 2, xf, yf, True, True)
+    gy2, gx2, gyf2, gxf2 = _C.chamfer_backward(y, x, idx_yx, yl, xl, None, g, 2, yf, xf, True, True)
+    want = [gx + gx2, gy + gy2, gxf[0] + gxf2[0], gyf[0] + gyf2[0]]
+    _C.chamfer_backward(y, x, idx_yx, yl, xl, None, g, 2, yf, xf, True, True, into=(gy, gx, gyf, gxf))
+    for got, ref in zip([gx, gy, gxf[0], gyf[0]], want):
+        assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6)
+    assert bool((gx[1, 333:] == 0).all()) and bool((gy[1, 10:] == 0).all())
+    with pytest.raises(RuntimeError, match="into"):
+        _C.chamfer_backward(y, x, idx_yx, yl, xl, None, g, 2, yf, xf, True, True, into=(gx, gy, gxf, gyf))
