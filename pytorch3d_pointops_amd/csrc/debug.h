@@ -3,7 +3,8 @@
 // read at call time (one getenv per lookup, only on host launch paths).  Unset = every knob at its
 // default; no knob ever changes results, only which exact path computes them.
 //   knn_generic=1      knn_wide's plain generic kernel instead of its LDS-tiled forms
-//   grid_quad=0|1      force the quad pass of the grid KNN off / on (default: by cloud size)
+//   grid_quad=0|1      force the quad pass of the grid KNN off / on (default: by the batch's query count)
+//   grid_long_box=0|1  K in (32, 64]: uncertified queries to the wave search / to the box search (default: by query count)
 //   grid_refine=0      no refined cells (over-full neighbourhoods still go to the box search, over whole cells)
 //   grid_same=0        do not reuse the point sort as the query order when p1 is p2
 //   grid_c_scale=F     multiply the grid KNN's points-per-cell target (sweeps)

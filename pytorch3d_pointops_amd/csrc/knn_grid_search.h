@@ -2,6 +2,7 @@
 // exactness argument and the pass list are in knn_grid.hip.  Templates only: the translation units
 // knn_grid_d*.hip instantiate them per point dimension so that they compile in parallel.
 #pragma once
+#include "debug.h"
 #include "grid.h"
 #include "knn_common.h"
 #include "sort_net.h"
@@ -297,9 +298,9 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
         const int64_t row = (int64_t)n * P1 + qi;
         write_row_f64<KC>(top, K, g.len2, idxs + row * K, dists + row * K);
       } else if (overlong || uncertified_to_box) {
-        // (long lists have no quad pass: on big clouds their uncertified queries take the box search -- one lane per
+        // (long lists have no quad pass: in big batches their uncertified queries take the box search -- one lane per
         // query, a box sized from the local density -- instead of the wave-per-query search: 1.5 ms of the 5.1 ms at
-        // K=64, cfg2 size; small clouds send too few of them to fill the box kernel: 0.33 vs 0.69 ms at 4 x 16384)
+        // K=64, cfg2 size; see long_lists_to_box)
         const int pos = atomicAdd(box_count + n, 1);
         box_list[(int64_t)n * P1 + pos] = qi;
       } else {
@@ -697,6 +698,15 @@ __global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
 template <int D, int KC, int NORM>
 static void launch_grid_box(const KnnArgs& a, const GridWs& ws, bool quad);  // knn_grid_box.h
 
+// 64-slot lists have no quad pass: their uncertified queries take the box search when the batch sends it enough of them
+// to fill the chip, else the wave search directly (K=64, ms with / without: 32 x 65536 queries 3.09 / 3.91, 64 x 16384
+// 2.69 / 2.66, 8 x 65536 1.16 / 1.10, 8 x 32768 0.87 / 0.69, 2 x 65536 0.74 / 0.38); debug knob grid_long_box=0/1 forces
+// the choice
+static inline bool long_lists_to_box(const KnnArgs& a) {
+  const long k = debug_knob("grid_long_box", -1);
+  return k >= 0 ? k != 0 : a.N * (int64_t)a.P1 >= (3LL << 19);
+}
+
 template <int D, int KC, int NORM>
 static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
   // One wave64 per workgroup and ONE chunk of 64 queries per workgroup where the launch allows it (a multiple of 8: the
@@ -709,7 +719,7 @@ static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
                      (const GridCloud*)ws.cloud, (const int*)ws.chunk_prefix, (const float*)ws.edges,
                      (const int*)ws.cell_start, (const float4*)ws.sorted, (const float4*)ws.qsorted, ws.fb_count,
                      ws.fb_list, ws.fb_kth, ws.box_count, ws.box_list, kDeferFactor * refine_threshold(ws.c_target),
-                     (KC > 32 && a.P1 >= 32768) ? 1 : 0, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
+                     (KC > 32 && long_lists_to_box(a)) ? 1 : 0, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
   if constexpr (KC <= 32) if (quad) {
     int64_t wx = a.P1 / (32 * kQuadQueries);  // a few % of a cloud arrive here
     wx = wx < 8 ? 8 : wx > 4096 ? 4096 : wx;
