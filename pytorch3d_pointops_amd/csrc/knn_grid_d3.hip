@@ -10,9 +10,3 @@ void grid_search_d3(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool q
 }
 
 }  // namespace pointops
-
-#ifdef POINTOPS_LANE_STAMPS
-extern "C" int pointops_debug_lane_stamps(void* dst, size_t bytes) {
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pointops::g_lane_stamps), bytes, 0, hipMemcpyDeviceToHost);
-}
-#endif

@@ -56,12 +56,10 @@ constexpr int kLaneRows = 9;
 template <int KC>
 struct LaneCfg {
   static constexpr bool kUseQueue = KC >= 8;
-#ifndef POINTOPS_LANE_QUEUE
-#define POINTOPS_LANE_QUEUE 16
-#endif
-  static constexpr int kQueueCap = POINTOPS_LANE_QUEUE;  // keys a flush sorts (a sorting network: 8 or 16)
-  // per-lane LDS queue slots
-  static constexpr int kQueueLds = kQueueCap == 16 ? (KC <= 16 ? 15 : 16) : kQueueCap;
+  static constexpr int kQueueCap = 16;                  // keys a flush sorts (KC = 8 merges the 8 smallest)
+  // per-lane LDS queue slots: 15 of them + the 2.5 KB run table = 10 KB per wave, SIXTEEN waves per CU (the VGPR limit of
+  // the K <= 16 kernels) instead of fifteen: cfg2 0.715 -> 0.703 ms per step (14 slots: 0.707)
+  static constexpr int kQueueLds = KC <= 16 ? 15 : 16;
 #ifndef POINTOPS_LANE_GROUP
 #define POINTOPS_LANE_GROUP 4  // 8 measured 0.776 vs 0.755 ms at cfg2 (K=16), 1.46 vs 1.31 ms at K=32: fewer masked slots
 #endif                         // (a run of ~19 records wastes 1.5 of 4 against 3.5 of 8) beat the fewer, wider groups
@@ -80,13 +78,7 @@ struct LaneCfg {
 // ---------------------------------------------------------------------------
 constexpr int kRunBits = 11, kRunMax = (1 << kRunBits) - 1;
 
-// STAGED: `spb` is the wave's LDS image of the records (knn_grid_lane_kernel) and the run words count in records of
-// that image; otherwise the cloud's sorted array in global memory.
-using LdsBytes = const __attribute__((address_space(3))) char*;
-typedef float lds_f4 __attribute__((ext_vector_type(4)));
-using LdsRecord = const __attribute__((address_space(3))) lds_f4*;
-
-template <int D, int KC, int NORM, int ROWS, bool STAGED = false>
+template <int D, int KC, int NORM, int ROWS>
 __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const unsigned* rows, int lane,
                                           double* s_queue, float qx, float qy, float qz, unsigned thr0,
                                           TopKF64<KC>& top) {
@@ -120,12 +112,7 @@ __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const un
     }
   };
   auto record = [&](unsigned o, int u) __attribute__((always_inline)) -> float4 {
-    if constexpr (STAGED) {  // ds_read_b128, immediate offset
-      const lds_f4 v = *(LdsRecord)((LdsBytes)spb + o + (unsigned)(16 * u));
-      return make_float4(v.x, v.y, v.z, v.w);
-    } else {
-      return *(const float4*)(spb + o + (unsigned)(16 * u));  // saddr + 32-bit voffset + immediate
-    }
+    return *(const float4*)(spb + o + (unsigned)(16 * u));  // saddr + 32-bit voffset + immediate
   };
 
   unsigned thr = thr0;
@@ -154,16 +141,13 @@ __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const un
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < kSub; ++t) {
-      // a record past the run's end compares as 0xffffffff, above every threshold: no second condition, so the
-      // distances stay outside the branches (a short-circuit `valid && d <= thr` let the compiler sink each distance
-      // behind its own branch and rotate the record registers with copies)
-      const unsigned dm = __float_as_uint(dd[t]) | (unsigned)((crem - 1 - 16 * (u0 + t)) >> 31);
+      const bool valid = 16 * (u0 + t) < crem;
       if (kUseQueue) {
-        if (dm <= thr) {
+        if (valid && __float_as_uint(dd[t]) <= thr) {
           s_queue[qn] = TopKF64<KC>::make(dd[t], ii[t]);
           qn += kGridWave;
         }
-      } else if (dm <= min(top.worst_bits(), thr0)) {
+      } else if (valid && __float_as_uint(dd[t]) <= min(top.worst_bits(), thr0)) {
         top.insert(TopKF64<KC>::make(dd[t], ii[t]));
       }
     }
@@ -207,26 +191,6 @@ __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const un
   }
 }
 
-// LDS image of a chunk's candidate records.  The 64 queries of a chunk are consecutive in cell order, so their cells
-// are the ids a .. b of a short range and the nine (dy, dz) rows of every lane's cube lie inside the nine ranges of
-// cell ids [a + off - 1, b + off + 1], off = (dz G1 + dy) G0 -- nine CONTIGUOUS pieces of the cell-sorted array (about
-// 9 (b - a + 3) cells, ~700 records at the usual occupancies).  The wave copies them into LDS once with coalesced 16-byte
-// loads and every lane then walks its runs with ds_read_b128 (LDS latency, 256 B/clk) instead of per-lane 16-byte
-// gathers through the texture path: round 2's lane search waited on those gathers for a third of its cycles with the
-// VALU busy 16 % of the time.  A chunk whose pieces exceed the image (clouds whose queries sit where the points are
-// sparse or dense beyond the grid's target) walks the global array as before.
-#ifndef POINTOPS_STAGE_CAP
-#define POINTOPS_STAGE_CAP 960
-#endif
-#ifdef POINTOPS_LANE_STAMPS  // diagnostic builds only (tools/lane_stamps.py): s_memtime at the phase boundaries of a chunk
-__device__ long long g_lane_stamps[(1 << 16) * 8];
-#define PO_STAMP(k) do { if (threadIdx.x == 0 && item < (1 << 16)) g_lane_stamps[item * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define PO_STAMP(k) do { } while (0)
-#endif
-constexpr int kStageCap = POINTOPS_STAGE_CAP;  // records of the image (+ the group-tail pad)
-constexpr int kStageBatch = 12;                // 64-record blocks loaded together (all in flight before the first LDS store)
-
 // (second launch bound = waves per SIMD the compiler has to leave room for: the 64-slot list needs 261 registers
 // without it, five more than two waves allow)
 template <int D, int KC, int NORM>
@@ -235,24 +199,18 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
     const float* __restrict__ edges, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
     const float4* __restrict__ qsorted, int* __restrict__ fb_count, int* __restrict__ fb_list,
     unsigned* __restrict__ fb_kth, int* __restrict__ box_count, int* __restrict__ box_list, int defer_limit,
-    int uncertified_to_box, int stage, int cell_cap, int P1, int P2, int K, int N, int64_t* __restrict__ idxs,
-    float* __restrict__ dists) {
+    int uncertified_to_box, int cell_cap, int P1, int P2, int K, int N, int64_t* __restrict__ idxs, float* __restrict__ dists) {
   using Cfg = LaneCfg<KC>;
   constexpr bool kUseQueue = Cfg::kUseQueue;
   constexpr int kQueueCap = Cfg::kQueueLds;
   constexpr int kSub = Cfg::kSub;
   constexpr int G = Cfg::kGroup;
-#ifndef POINTOPS_LANE_STAGE
-#define POINTOPS_LANE_STAGE 0
-#endif
-  constexpr bool kStaged = POINTOPS_LANE_STAGE != 0 && KC <= 32;  // (64-slot lists: cells of 26 points, a chunk's pieces rarely fit)
   static_assert(G % kSub == 0 && G <= kSortedPad, "group geometry");
   __shared__ double s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
   // per-lane list of its non-empty runs, one word each: first record << 11 | length (<= 2047; a lane with a longer
   // run -- an over-full cell -- leaves its query to the fallback passes), then zeros.  Packed so that a wave needs
-  // 2.5 KB instead of 5 KB of LDS.
+  // 2.5 KB instead of 5 KB of LDS: with the 8 KB queue that is 15 instead of 12 waves per CU.
   __shared__ unsigned s_rows[kLaneRows + 1][kGridWave];
-  __shared__ float4 s_stage[kStaged ? kStageCap + kSortedPad : 1];
 
   const int lane = threadIdx.x;
   const int total = chunk_prefix[N];
@@ -269,7 +227,6 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
   for (int j = blockIdx.x / kNumXcd; j < per_xcd; j += gridDim.x / kNumXcd) {
     const int item = xcd * per_xcd + j;
     if (item >= total) break;
-    PO_STAMP(0);
     const int n = item_cloud(chunk_prefix, N, item, (P1 + kGridWave - 1) / kGridWave);
     const GridCloud g = clouds[n];
     const int c0 = (item - chunk_prefix[n]) * kGridWave;
@@ -290,63 +247,6 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
     const int Y0 = max(cy - 1, 0), Y1 = min(cy + 1, g.G[1] - 1);
     const int Z0 = max(cz - 1, 0), Z1 = min(cz + 1, g.G[2] - 1);
     const int* __restrict__ cstart = cell_start + (int64_t)n * (cell_cap + 1);
-#ifdef POINTOPS_LANE_STAMPS
-    if (__builtin_amdgcn_readfirstlane(cx) >= 0) PO_STAMP(1);  // (the query record has arrived)
-#endif
-
-    // ---- the chunk's nine pieces: lane s < 9 owns piece (dy, dz) = (s % 3 - 1, s / 3 - 1)
-    bool staged = false;
-    int piece_delta = 0, piece_pos = 0;  // lane s: first record of the piece minus its position in the image; position
-    if constexpr (kStaged) {
-      const int nact = min(g.len1 - c0, kGridWave);  // >= 1
-      const int cid = (cz * g.G[1] + cy) * g.G[0] + cx;
-      const int ca = __builtin_amdgcn_readfirstlane(cid), cb = __shfl(cid, nact - 1, kGridWave);  // cell order: min, max
-      int first = 0, len = 0;
-      if (lane < 9) {
-        const int dy = lane % 3 - 1, dz = lane / 3 - 1;
-        const int off = (dz * g.G[1] + dy) * g.G[0];
-        const int lo = max(ca + off - 1, 0), hi = min(cb + off + 1, g.ncell - 1);
-        if (hi >= lo) {
-          first = cstart[lo];
-          len = cstart[hi + 1] - first;
-        }
-      }
-      int inc = len;  // inclusive scan over the nine lanes
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        const int v = __shfl_up(inc, o, kGridWave);
-        if (lane >= o) inc += v;
-      }
-      const int T = __shfl(inc, 8, kGridWave);
-      piece_pos = inc - len;
-      piece_delta = first - piece_pos;
-      staged = stage != 0 && T <= kStageCap;  // (wave-uniform)
-      PO_STAMP(2);
-      if (staged) {
-        int ppos[9], pdelta[9];
-#pragma unroll
-        for (int s2 = 0; s2 < 9; ++s2) {
-          ppos[s2] = __builtin_amdgcn_readlane(piece_pos, s2);
-          pdelta[s2] = __builtin_amdgcn_readlane(piece_delta, s2);
-        }
-        for (int j0 = 0; j0 * kGridWave < T; j0 += kStageBatch) {
-          float4 buf[kStageBatch];
-#pragma unroll
-          for (int u = 0; u < kStageBatch; ++u) {
-            const int t = (j0 + u) * kGridWave + lane;
-            int d = pdelta[0];  // the piece of image position t: the last one that starts at or before it
-#pragma unroll
-            for (int s2 = 1; s2 < 9; ++s2) d = t >= ppos[s2] ? pdelta[s2] : d;
-            buf[u] = sp[t < T ? t + d : 0];  // (unconditional: a conditionally written array goes through scratch)
-          }
-#pragma unroll
-          for (int u = 0; u < kStageBatch; ++u) {
-            const int t = (j0 + u) * kGridWave + lane;
-            if (t < T) s_stage[t] = buf[u];
-          }
-        }
-      }
-    }
 
     // rigorous lower bound of every point outside the lane's cube (certification), known before the
     // walk: it also seeds the candidate threshold
@@ -362,30 +262,18 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
     {
       int cnt = 0;  // rows written so far, as an element offset into s_rows
       int total = 0;
-      constexpr int kDz[kLaneRows] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
-      constexpr int kDy[kLaneRows] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
-      // all eighteen run bounds in flight together (rows outside the grid read the own row's: loads inside the
-      // per-row branches cost one memory latency per row, 9 000 cycles of a chunk's 80 000)
-      int rs[kLaneRows], re[kLaneRows];
 #pragma unroll
       for (int r = 0; r < kLaneRows; ++r) {
+        constexpr int kDz[kLaneRows] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+        constexpr int kDy[kLaneRows] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
         const int z = cz + kDz[r], y = cy + kDy[r];
-        const bool in = z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1];
-        const int rowbase = ((in ? z : cz) * g.G[1] + (in ? y : cy)) * g.G[0];
-        rs[r] = cstart[rowbase + X0];
-        re[r] = cstart[rowbase + X1 + 1];
-      }
-#pragma unroll
-      for (int r = 0; r < kLaneRows; ++r) {
-        const int z = cz + kDz[r], y = cy + kDy[r];
-        // image coordinates: record i of the cloud sits at i - delta of the row's piece
-        const int delta = (kStaged && staged) ? __builtin_amdgcn_readlane(piece_delta, (kDz[r] + 1) * 3 + kDy[r] + 1) : 0;
         if (active && z >= 0 && z < g.G[2] && y >= 0 && y < g.G[1]) {
-          const int s = rs[r], e = re[r];
+          const int rowbase = (z * g.G[1] + y) * g.G[0];
+          const int s = cstart[rowbase + X0], e = cstart[rowbase + X1 + 1];
           if (e > s) {
             overlong = overlong || e - s > kRunMax;
             total += e - s;
-            rows[lane + cnt] = ((unsigned)(s - delta) << kRunBits) | (unsigned)min(e - s, kRunMax);
+            rows[lane + cnt] = ((unsigned)s << kRunBits) | (unsigned)min(e - s, kRunMax);
             cnt += kGridWave;
           }
         }
@@ -400,22 +288,9 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
     }
     TopKF64<KC> top;
     top.init();
-#ifdef POINTOPS_LANE_STAMPS
-    if (__builtin_amdgcn_readfirstlane((int)rows[lane]) != -7) PO_STAMP(3);  // (run list written)
-#endif
-    if (kStaged && staged) {
-      __syncthreads();  // (one wave: orders the image's stores before the other lanes' reads)
-      PO_STAMP(4);
-      lane_walk<D, KC, NORM, kLaneRows, true>((const char*)s_stage, rows, lane, s_queue, qx, qy, qz, thr0, top);
-      __syncthreads();  // (the next chunk overwrites the image)
-    } else {
-      lane_walk<D, KC, NORM, kLaneRows, false>((const char*)sp, rows, lane, s_queue, qx, qy, qz, thr0, top);
-    }
+    lane_walk<D, KC, NORM, kLaneRows>((const char*)sp, rows, lane, s_queue, qx, qy, qz, thr0, top);
 
     const unsigned kth_bits = top.kth_bits(K);  // the K-th best, not the list's last slot
-#ifdef POINTOPS_LANE_STAMPS
-    if (__builtin_amdgcn_readfirstlane((int)kth_bits) != -7) PO_STAMP(5);  // (walk finished)
-#endif
     const bool full = kth_bits < 0x7f800000u;
     const bool ok = !overlong && (whole || (full && __uint_as_float(kth_bits) < lb));
     if (active) {
@@ -442,7 +317,6 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
         fb_kth[(int64_t)n * P1 + pos] = __float_as_uint(est);
       }
     }
-    PO_STAMP(6);
   }
 }
 
@@ -845,8 +719,7 @@ static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
                      (const GridCloud*)ws.cloud, (const int*)ws.chunk_prefix, (const float*)ws.edges,
                      (const int*)ws.cell_start, (const float4*)ws.sorted, (const float4*)ws.qsorted, ws.fb_count,
                      ws.fb_list, ws.fb_kth, ws.box_count, ws.box_list, kDeferFactor * refine_threshold(ws.c_target),
-                     (KC > 32 && long_lists_to_box(a)) ? 1 : 0, (int)debug_knob("grid_stage", 1), ws.cell_cap, a.P1, a.P2, a.K,
-                     (int)a.N, a.idxs, a.dists);
+                     (KC > 32 && long_lists_to_box(a)) ? 1 : 0, ws.cell_cap, a.P1, a.P2, a.K, (int)a.N, a.idxs, a.dists);
   if constexpr (KC <= 32) if (quad) {
     int64_t wx = a.P1 / (32 * kQuadQueries);  // a few % of a cloud arrive here
     wx = wx < 8 ? 8 : wx > 4096 ? 4096 : wx;
