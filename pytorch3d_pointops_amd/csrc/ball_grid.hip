@@ -215,8 +215,14 @@ __device__ __forceinline__ int order_bin(const float* __restrict__ q, const unsi
   return bin;
 }
 
-// SCATTER = false: histogram into order_count; true: exclusive scan of the counters (every block, in LDS)
-// + scatter through the cursors in order_cursor
+static_assert(kOrderBlock * kOrderPerThread == 2048, "order_table is sized for tiles of 2048 queries");
+
+// Counting sort of the query ids by coarse cell WITHOUT device atomics (round 2 drew every list position from a
+// per-cell cursor in memory: 2 M atomics on 4096 hot counters per cloud, 139 us at cfg3):
+//   count    every tile of 2048 queries writes its whole LDS histogram to order_table[n][tile][cell] (no zeroing pass);
+//   scan     per cloud: per cell the exclusive prefix over the tiles, then the exclusive scan of the cell totals;
+//            order_table[n][tile][cell] becomes the list position of the tile's first query of that cell;
+//   scatter  the tile ranks its queries per cell in LDS again and stores the ids.
 template <int D, bool SCATTER>
 __global__ __launch_bounds__(kOrderBlock) void ball_order_kernel(const float* __restrict__ p1, int P1, GridWs ws) {
   const int n = blockIdx.y;
@@ -226,81 +232,101 @@ __global__ __launch_bounds__(kOrderBlock) void ball_order_kernel(const float* __
   const int tid = threadIdx.x;
   const int i0 = blockIdx.x * (kOrderBlock * kOrderPerThread);
   if (i0 >= g.len1) return;
-  int* __restrict__ count = ws.order_count + (int64_t)n * kOrderBins;
-  int* __restrict__ cursor = ws.order_cursor + (int64_t)n * kOrderBins;
-  for (int b = tid; b < kOrderBins; b += kOrderBlock) s_bin[b] = SCATTER ? count[b] : 0;
+  int* __restrict__ table = ws.order_table + ((int64_t)n * gridDim.x + blockIdx.x) * kOrderBins;
+  for (int b = tid; b < kOrderBins; b += kOrderBlock) s_bin[b] = 0;
   __syncthreads();
-  if (SCATTER) {  // exclusive scan of the counters: kPer per lane + wave scan + 4 wave totals
-    __shared__ int s_tot[kOrderBlock / kWave];
-    constexpr int kPer = kOrderBins / kOrderBlock;
-    int v[kPer];
-    int inc = 0;
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-      v[u] = s_bin[kPer * tid + u];
-      inc += v[u];
-    }
-    const int mine = inc;
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const int v = __shfl_up(inc, off, kWave);
-      if (lane >= off) inc += v;
-    }
-    if (lane == kWave - 1) s_tot[wave] = inc;
-    __syncthreads();
-    int run = inc - mine;
-    for (int w = 0; w < wave; ++w) run += s_tot[w];
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-      s_bin[kPer * tid + u] = run;
-      run += v[u];
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && tid == 0) ws.fb2_count[n] = g.len1;  // the list holds every query of the cloud
-  }
   const unsigned* __restrict__ bbox = ws.bbox + n * 8;
+  int bin[kOrderPerThread], rank[kOrderPerThread];
 #pragma unroll
   for (int r = 0; r < kOrderPerThread; ++r) {
     const int i = i0 + r * kOrderBlock + tid;
+    bin[r] = -1;
     if (i < g.len1) {
-      const int bin = order_bin<D>(p1 + ((int64_t)n * P1 + i) * D, bbox);
-      if (!SCATTER) {
-        atomicAdd(&s_bin[bin], 1);
-      } else {
-        const int pos = s_bin[bin] + atomicAdd(cursor + bin, 1);
-        ws.fb2_list[(int64_t)n * P1 + pos] = i;
-      }
+      bin[r] = order_bin<D>(p1 + ((int64_t)n * P1 + i) * D, bbox);
+      rank[r] = atomicAdd(&s_bin[bin[r]], 1);
     }
   }
   if (!SCATTER) {
     __syncthreads();
-    for (int b = tid; b < kOrderBins; b += kOrderBlock)
-      if (s_bin[b] > 0) atomicAdd(count + b, s_bin[b]);
+    for (int b = tid; b < kOrderBins; b += kOrderBlock) table[b] = s_bin[b];
+  } else {
+#pragma unroll
+    for (int r = 0; r < kOrderPerThread; ++r)
+      if (bin[r] >= 0) ws.fb2_list[(int64_t)n * P1 + table[bin[r]] + rank[r]] = i0 + r * kOrderBlock + tid;
   }
 }
 
-// PHASE 0: zero the counters and cursors of the scan-mode clouds; PHASE 1, behind the scatter: mark those clouds as "listed"
-template <int PHASE>
-__global__ void ball_order_aux_kernel(GridWs ws, int N) {
+constexpr int kOrderScanBlock = 1024;
+__global__ __launch_bounds__(kOrderScanBlock) void ball_order_scan_kernel(GridWs ws, int tiles_cap) {
   const int n = blockIdx.x;
   const GridCloud g = ws.cloud[n];
   if (g.use_grid || g.len2 <= 0) return;
-  if (PHASE == 0) {
-    for (int b = threadIdx.x; b < kOrderBins; b += blockDim.x) {
-      ws.order_count[(int64_t)n * kOrderBins + b] = 0;
-      ws.order_cursor[(int64_t)n * kOrderBins + b] = 0;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int tiles = (g.len1 + 2047) / 2048;
+  int* __restrict__ table = ws.order_table + (int64_t)n * tiles_cap * kOrderBins;
+  constexpr int kPer = kOrderBins / kOrderScanBlock;  // consecutive cells per thread
+  int tot[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) tot[u] = 0;
+  static_assert(kPer == 4, "one int4 per thread");
+  constexpr int kBatch = 16;  // tiles in flight (one load at a time: 64 dependent round trips, 91 us at cfg3)
+  int4* __restrict__ col = (int4*)table + tid;  // this thread's four cells, tile t at col[t * (kOrderBins / 4)]
+  for (int t0 = 0; t0 < tiles; t0 += kBatch) {  // per cell: exclusive prefix over the tiles
+    int4 v[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u)
+      v[u] = t0 + u < tiles ? col[(int64_t)(t0 + u) * (kOrderBins / 4)] : make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      if (t0 + u < tiles) col[(int64_t)(t0 + u) * (kOrderBins / 4)] = make_int4(tot[0], tot[1], tot[2], tot[3]);
+      tot[0] += v[u].x;
+      tot[1] += v[u].y;
+      tot[2] += v[u].z;
+      tot[3] += v[u].w;
     }
-  } else if (threadIdx.x == 0) {
-    ws.grid_flag[n] = 1;
+  }
+  // exclusive scan of the cell totals over the workgroup: list positions in cell order.  (Measured and dropped: the
+  // cells whose balls the bounding box clips -- the long scans -- first in the list: 662 -> 776 us for the scan kernel.)
+  __shared__ int s_tot[kOrderScanBlock / kWave];
+  const int mine = tot[0] + tot[1] + tot[2] + tot[3];
+  int inc = mine;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int v = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += v;
+  }
+  if (lane == kWave - 1) s_tot[wave] = inc;
+  __syncthreads();
+  int run = inc - mine;
+  for (int w = 0; w < wave; ++w) run += s_tot[w];
+  int start[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    start[u] = run;
+    run += tot[u];
+  }
+  for (int t0 = 0; t0 < tiles; t0 += kBatch) {
+    int4 v[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u)
+      v[u] = t0 + u < tiles ? col[(int64_t)(t0 + u) * (kOrderBins / 4)] : make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      if (t0 + u < tiles)
+        col[(int64_t)(t0 + u) * (kOrderBins / 4)] =
+            make_int4(v[u].x + start[0], v[u].y + start[1], v[u].z + start[2], v[u].w + start[3]);
+    }
+  }
+  if (tid == 0) {
+    ws.fb2_count[n] = g.len1;  // the list holds every query of the cloud
+    ws.grid_flag[n] = 1;       // "listed" (stream order: the scatter launch follows, the scan kernel after it)
   }
 }
 
 constexpr float kBallCellTarget = 2.0f;  // density floor of the cell size; the radius usually decides
 
 size_t ball_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2) {
-  return grid_carve(nullptr, nullptr, N, P1, P2, kBallCellTarget);
+  return grid_carve(nullptr, nullptr, N, P1, P2, kBallCellTarget, true);
 }
 
 template <int D>
@@ -324,7 +350,7 @@ int ball_grid_run(const KnnArgs& a, float radius, void* workspace, const int** f
                   const int** qlist) {
   POINTOPS_REQUIRE(a.N < 65536 && a.P2 <= (1 << 20) && a.K <= 64 && a.D <= 3, "ball_query(grid): unsupported shape");
   GridWs ws;
-  grid_carve(&ws, (char*)workspace, a.N, a.P1, a.P2, kBallCellTarget);
+  grid_carve(&ws, (char*)workspace, a.N, a.P1, a.P2, kBallCellTarget, true);
   ws.ball = 1;
   GridBuild b{};
   b.c_target = kBallCellTarget;
@@ -349,9 +375,10 @@ int ball_grid_run(const KnnArgs& a, float radius, void* workspace, const int** f
   // scan-mode clouds: all queries, ordered by coarse cell
   if (debug_knob("ball_order", 1) != 0) {
     const dim3 og((unsigned)ceil_div(a.P1, kOrderBlock * kOrderPerThread), (unsigned)a.N);
-    hipLaunchKernelGGL(ball_order_aux_kernel<0>, dim3((unsigned)a.N), dim3(256), 0, a.stream, ws, (int)a.N);
 #define PO_ORDER(DD)                                                                                         \
   hipLaunchKernelGGL((ball_order_kernel<DD, false>), og, dim3(kOrderBlock), 0, a.stream, a.p1, a.P1, ws);     \
+  hipLaunchKernelGGL(ball_order_scan_kernel, dim3((unsigned)a.N), dim3(kOrderScanBlock), 0, a.stream, ws,    \
+                     (int)og.x);                                                                             \
   hipLaunchKernelGGL((ball_order_kernel<DD, true>), og, dim3(kOrderBlock), 0, a.stream, a.p1, a.P1, ws)
     switch (a.D) {
       case 1: PO_ORDER(1); break;
@@ -359,7 +386,6 @@ int ball_grid_run(const KnnArgs& a, float radius, void* workspace, const int** f
       default: PO_ORDER(3); break;
     }
 #undef PO_ORDER
-    hipLaunchKernelGGL(ball_order_aux_kernel<1>, dim3((unsigned)a.N), dim3(64), 0, a.stream, ws, (int)a.N);
   }
   *flag = ws.grid_flag;
   *qcount = ws.fb2_count;

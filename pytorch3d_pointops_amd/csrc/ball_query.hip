@@ -258,6 +258,187 @@ __global__ __launch_bounds__(kBqBlock) void ball_query_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// LISTED clouds with the hits STAGED IN LDS (D <= 4, K <= 64): one wave per workgroup, the tile scan of the
+// kernel above, but a hit goes to the lane's row of an LDS image of the wave's 64 output rows (index as 32 bits +
+// distance) instead of straight to memory, and every lane writes its finished row -- padding included -- with 16-byte
+// stores.  The per-hit `orow_i[count] = j; orow_d[count] = d` of the kernel above is one 8-byte and one 4-byte store
+// per lane into 64 different rows per instruction: measured at cfg3 (16 x 131072, r = 0.2, K = 32) WRITE_SIZE 3.2 GB
+// for 0.8 GB of output, 70 % of the wave-cycles waiting for an issue slot behind the store queue
+// (profiles/r03_ball_a_pmc.json).
+// Row stride = 4 (2 ceil(K / 8) + 1) dwords: rows stay 16-byte aligned and the lanes' ds_read_b128 of their own rows
+// fall into distinct banks.
+// ---------------------------------------------------------------------------
+__host__ __device__ inline int ball_stage_stride(int K) { return 4 * (2 * ((K + 7) / 8) + 1); }
+
+#ifndef POINTOPS_BALL_LIST_WAVES
+#define POINTOPS_BALL_LIST_WAVES 1
+#endif
+constexpr int kBqListWaves = POINTOPS_BALL_LIST_WAVES;  // independent waves per workgroup
+
+template <int DT>
+__global__ __launch_bounds__(kWave * kBqListWaves) void ball_query_list_kernel(
+    const float* __restrict__ p1, const float* __restrict__ p2, const int64_t* __restrict__ lengths1,
+    const int64_t* __restrict__ lengths2, int P1, int P2, int K, float radius2, const int* __restrict__ grid_flag,
+    const int* __restrict__ qcount, const int* __restrict__ qlist, int64_t* __restrict__ idxs,
+    float* __restrict__ dists) {
+  extern __shared__ unsigned s_stage[];  // [64][stride] indices of the hits (distances are recomputed when the rows are
+                                         // written: half the LDS, twice the waves per CU -- 5 resident of 8 possible
+                                         // with the distances staged too, and the scan then waits on memory)
+  const int n = blockIdx.y;
+  const bool listed = grid_flag[n] != 0;  // (a cloud without a list -- empty, or ordering switched off: storage order)
+  const int cnt = listed ? qcount[n] : P1;
+  const int lane = threadIdx.x & (kWave - 1), wslot = threadIdx.x / kWave;
+  const int base = (blockIdx.x * kBqListWaves + wslot) * kWave;
+  if (base >= cnt) return;
+  const bool in_range = base + lane < cnt;
+  const int i = !in_range ? 0 : listed ? qlist[(int64_t)n * P1 + base + lane] : base + lane;
+  const int len1 = (int)lengths1[n];
+  int len2 = (int)lengths2[n];
+  if (len2 > P2) len2 = P2;
+  const int64_t row = (int64_t)n * P1 + i;
+  const bool active = in_range && i < len1;
+  const int stride = ball_stage_stride(K);
+  unsigned* const my_i = s_stage + (wslot * kWave + lane) * stride;
+  for (int k = 0; k < stride; k += 4)  // the row starts as padding: idx -1 (ball_query_cpu.cpp:20-21)
+    *(uint4*)(my_i + k) = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+  int count = 0;
+  const float* __restrict__ q = p2 + (int64_t)n * P2 * DT;
+  float a[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) a[d] = active ? p1[row * DT + d] : 0.0f;
+  auto dist_to = [&](const float* __restrict__ b) {
+    float acc;
+    {
+      const float diff = a[0] - b[0];
+      acc = diff * diff;
+    }
+#pragma unroll
+    for (int d = 1; d < DT; ++d) {
+      const float diff = a[d] - b[d];
+      acc = acc + diff * diff;
+    }
+    return acc;
+  };
+  const int room = active ? K : 0;
+  // bounding box of the wave's active queries (exact min / max): see ball_query_kernel
+  float blo[DT], bhi[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    float mn = active ? a[d] : __builtin_inff(), mx = active ? a[d] : -__builtin_inff();
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, off, kWave));
+      mx = fmaxf(mx, __shfl_xor(mx, off, kWave));
+    }
+    blo[d] = mn;
+    bhi[d] = mx;
+  }
+  int j0 = 0;
+  float cn[DT];  // the NEXT tile's point of this lane, loaded one tile ahead
+#pragma unroll
+  for (int d = 0; d < DT; ++d) cn[d] = lane < len2 ? q[(int64_t)lane * DT + d] : 0.0f;
+  while (j0 < len2 && __any(count < room)) {
+    const int jc = j0 + lane;
+    float c[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) c[d] = cn[d];
+    {
+      const int jn = jc + kWave;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) cn[d] = jn < len2 ? q[(int64_t)jn * DT + d] : 0.0f;
+    }
+    float lb;
+    {
+      float g0 = fmaxf(fmaxf(blo[0] - c[0], c[0] - bhi[0]), 0.0f);
+      lb = g0 * g0;
+#pragma unroll
+      for (int d = 1; d < DT; ++d) {
+        const float gd = fmaxf(fmaxf(blo[d] - c[d], c[d] - bhi[d]), 0.0f);
+        lb = lb + gd * gd;
+      }
+    }
+    unsigned long long cand = __ballot(jc < len2 && lb < radius2);
+    unsigned mlo = 0u, mhi = 0u;  // the lane's hits among the tile's points
+    if (__popcll(cand) >= 48 && j0 + kWave <= len2) {  // most of the tile survives: all 64 points through the scalar path
+      unsigned r0 = 0u, r1 = 0u;
+      auto push_hit = [&](unsigned& mask, float acc) __attribute__((always_inline)) {
+        asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "s"(radius2), "v"(acc) : "vcc");
+      };
+      for (int jj = 0; jj < 32; jj += 8) {
+        float t[8 * DT];
+#pragma unroll
+        for (int u = 0; u < 8 * DT; ++u) t[u] = q[(int64_t)(j0 + jj) * DT + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) push_hit(r0, dist_to(t + u * DT));
+      }
+      for (int jj = 32; jj < 64; jj += 8) {
+        float t[8 * DT];
+#pragma unroll
+        for (int u = 0; u < 8 * DT; ++u) t[u] = q[(int64_t)(j0 + jj) * DT + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) push_hit(r1, dist_to(t + u * DT));
+      }
+      mlo = __brev(r0);
+      mhi = __brev(r1);
+      cand = 0ull;
+    }
+    while (cand != 0ull) {  // wave-uniform
+      const int b = __builtin_ctzll(cand);
+      cand &= cand - 1ull;
+      float pb[DT];
+#pragma unroll
+      for (int d = 0; d < DT; ++d) pb[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c[d]), b));
+      const bool hit = dist_to(pb) < radius2;
+      const unsigned bit = 1u << (b & 31);
+      if (b < 32) mlo |= hit ? bit : 0u;
+      else mhi |= hit ? bit : 0u;
+    }
+    if (count >= room) mlo = mhi = 0u;
+    while (__any((mlo | mhi) != 0u)) {  // wave-uniform loop: every lane takes part in the shuffles
+      const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+      const bool has = m != 0ull;
+      const int b = has ? __builtin_ctzll(m) : 0;
+      float ph[DT];
+#pragma unroll
+      for (int d = 0; d < DT; ++d) ph[d] = __shfl(c[d], b, kWave);  // the tile still sits in the lanes
+      if (has) {
+        if (b < 32) mlo &= mlo - 1u;
+        else mhi &= mhi - 1u;
+        my_i[count] = (unsigned)(j0 + b);
+        ++count;
+        if (count >= room) mlo = mhi = 0u;
+      }
+    }
+    j0 += kWave;
+  }
+  // the lane's finished row: 16-byte pieces (two indices widened to int64, four distances recomputed from the chosen
+  // points with the scan's expression -- the same operands, bit-identical); the caller guarantees K % 4 == 0, so
+  // every row of the outputs is 16-byte aligned
+  if (in_range) {
+    int64_t* __restrict__ orow_i = idxs + row * K;
+    float* __restrict__ orow_d = dists + row * K;
+    for (int k = 0; k < K; k += 4) {
+      const uint4 v = *(const uint4*)(my_i + k);
+      const unsigned jv[4] = {v.x, v.y, v.z, v.w};
+      float pt[4][DT];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned jx = jv[u] == 0xffffffffu ? 0u : jv[u];  // (padding: any valid address; its distance is 0)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) pt[u][d] = q[(int64_t)jx * DT + d];
+      }
+      float dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dv[u] = jv[u] == 0xffffffffu ? 0.0f : dist_to(pt[u]);
+      *(longlong2*)(orow_i + k) = make_longlong2((long long)(int)v.x, (long long)(int)v.y);
+      *(longlong2*)(orow_i + k + 2) = make_longlong2((long long)(int)v.z, (long long)(int)v.w);
+      *(float4*)(orow_d + k) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    }
+  }
+}
+
 }  // namespace pointops
 
 using namespace pointops;
@@ -299,6 +480,24 @@ extern "C" int pointops_ball_query(const float* p1, const float* p2, const int64
     a.idxs = idxs; a.dists = dists; a.stream = stream;
     const int rc = ball_grid_run(a, radius, workspace, &flag, &qcount, &qlist);
     if (rc != POINTOPS_OK) return rc;
+  }
+  // listed clouds (every cloud once the lists exist) with hits staged in LDS: K a multiple of 4 up to 64
+  const bool staged = flag != nullptr && D <= 4 && K <= 64 && K % 4 == 0 && debug_knob("ball_stage", 1) != 0;
+  if (staged) {
+    const size_t lds = (size_t)kBqListWaves * kWave * ball_stage_stride((int)K) * sizeof(unsigned);
+    const dim3 lgrid((unsigned)ceil_div(P1, kWave * kBqListWaves), (unsigned)N);
+#define PO_LIST(DT)                                                                                               \
+  hipLaunchKernelGGL((ball_query_list_kernel<DT>), lgrid, dim3(kWave * kBqListWaves), lds, stream, p1, p2,       \
+                     lengths1, lengths2,                                                                          \
+                     (int)P1, (int)P2, (int)K, radius2, flag, qcount, qlist, idxs, dists)
+    switch (D) {
+      case 1: PO_LIST(1); break;
+      case 2: PO_LIST(2); break;
+      case 3: PO_LIST(3); break;
+      default: PO_LIST(4); break;
+    }
+#undef PO_LIST
+    return check_launch("ball_query(list)");
   }
   const dim3 grid((unsigned)(N * tiles)), block(kBqBlock);
 #define PO_LAUNCH(DT)                                                                            \

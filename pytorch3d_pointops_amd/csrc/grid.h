@@ -62,8 +62,8 @@ struct GridWs {
   int* qrank;         // N * P1
   float4* qtmp;       // N * P1         query records grouped by coarse bin
   float4* qsorted;    // N * P1         query records (x, y, z, idx bits) by cell: the query order of the lane searches
-  int* order_count;   // N * kOrderBins ball query: coarse query order of the scan-mode clouds (ball_grid.hip)
-  int* order_cursor;  // N * kOrderBins
+  int* order_table;   // N * ceil(P1 / 2048) * kOrderBins   ball query: coarse query order of the scan-mode clouds
+                      // (ball_grid.hip): queries per (2048-query tile, coarse cell), then their first list position
   int* fb_count;      // N          queries the lane search could not certify
   int* fb_list;       // N * P1
   unsigned* fb_kth;   // N * P1     estimated KC-th distance (fp32 bits) of an uncertified query: picks the quad pass's cube
@@ -123,7 +123,7 @@ __device__ __forceinline__ int sub_of(float x, float lo, float scale, int s) {
 }
 
 // workspace layout (grid_build.hip)
-size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, float c_target);
+size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, float c_target, bool ball = false);
 // bbox, cell size, edge tables, counting sorts of points and queries, chunk prefix; stream-ordered
 int grid_build(const KnnArgs& a, const GridWs& ws, const GridBuild& b);
 // build the sub-grids of the cells grid_build marked (grid_refine.hip); stream-ordered behind grid_build

@@ -824,7 +824,7 @@ static int grid_cell_cap(int64_t P2, float c_target) {
   return (int)(2 * cells + 64);
 }
 
-size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, float c) {
+size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, float c, bool ball) {
   const int cap = grid_cell_cap(P2, c);
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -850,8 +850,7 @@ size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, flo
   w.fine_count = (int*)take(sizeof(int) * (size_t)N * 2 * cap);
   w.prank = (int*)take(sizeof(int) * (size_t)N * (size_t)P2);
   w.qrank = (int*)take(sizeof(int) * (size_t)N * (size_t)P1);
-  w.order_count = (int*)take(sizeof(int) * (size_t)N * kOrderBins);
-  w.order_cursor = (int*)take(sizeof(int) * (size_t)N * kOrderBins);
+  w.order_table = (int*)take(ball ? sizeof(int) * (size_t)N * (size_t)((P1 + 2047) / 2048) * kOrderBins : 0);
   w.sorted = (float4*)take(sizeof(float4) * (size_t)N * (size_t)(P2 + kSortedPad));
   w.qsorted = (float4*)take(sizeof(float4) * (size_t)N * (size_t)P1);
   w.fb_count = (int*)take(sizeof(int) * (size_t)N);
