@@ -3,7 +3,7 @@
 (BASELINE.json configs[1]; metric "Mpoint-pairs/s (+ %HBM roofline) knn_points ...").
 
     python bench.py                                   # 1 GPU
-    python bench.py --gpus 4 --steps 20 --warmup 5    # spawns 4 ranks itself (one process per GPU, RCCL)
+    python bench.py --gpus 4 --steps 20 --warmup 5    # spawns 4 ranks itself (one process per GPU, RCCL); fails fast
     python bench.py --gpus 8 --scaling strong         # BASELINE.json configs[4]: B=256 split over the ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W      # the same ranks, external launcher
@@ -74,33 +74,87 @@ def _free_port():
     return port
 
 
-def launch_ranks(args) -> int:
-    """Parent of a self-launched multi-GPU run.  It never touches the GPU (device_count() does not
-    initialise HIP on this image), starts one fresh interpreter per rank, relays rank 0's JSON line and
-    returns non-zero if any rank fails."""
-    import torch
+def visible_gpus() -> int:
+    """GPUs this process would see, WITHOUT touching the HIP runtime (the parent of the ranks must stay free of it:
+    children are spawned from here).  KFD topology nodes with SIMDs are GPUs; *_VISIBLE_DEVICES narrows them."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                props = open(os.path.join(base, node, "properties")).read()
+            except OSError:
+                continue
+            for line in props.splitlines():
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except OSError:
+        return -1  # unknown: let the ranks find out
+    return n
 
-    have = torch.cuda.device_count()
-    if have < args.gpus:
+
+def launch_ranks(args, rank_cmd=None, wall_limit_s=None) -> int:
+    """Parent of a self-launched multi-GPU run.  It never touches the GPU runtime, starts one fresh interpreter per
+    rank, polls ALL of them, and fails fast: the first rank that exits non-zero (or the wall-clock limit) kills the
+    others -- a rank that dies before or inside an RCCL barrier would otherwise leave rank 0 waiting forever.
+    Relays rank 0's JSON line.  `rank_cmd` (tests) replaces the per-rank command line."""
+    have = visible_gpus()
+    if 0 <= have < args.gpus and rank_cmd is None:
         log(f"--gpus {args.gpus} needs {args.gpus} visible GPUs, this machine has {have}: not launching")
         return 2
+    if wall_limit_s is None:
+        wall_limit_s = float(os.environ.get("POINTOPS_BENCH_WALL_LIMIT_S", "1500"))
     env = dict(os.environ)
     env.update({"WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
                 "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    cmd = rank_cmd or ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+    import tempfile
+
+    out0 = tempfile.TemporaryFile()  # rank 0's stdout (a pipe nobody reads while polling could fill up)
     procs = []
     for r in range(args.gpus):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if any(rcs):
-        log(f"rank exit codes {rcs}: failing")
+        procs.append(subprocess.Popen(cmd, env=e, stdout=out0 if r == 0 else subprocess.DEVNULL,
+                                      start_new_session=True))
+    t0 = time.monotonic()
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0]} exited with code {rcs[bad[0]]}"
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() - t0 > wall_limit_s:
+            failed = f"wall-clock limit of {wall_limit_s:.0f} s reached"
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        log(f"{failed}: stopping the other ranks")
         for p in procs:
             if p.poll() is None:
-                p.kill()
+                try:
+                    os.killpg(p.pid, 15)  # the rank's own session: exactly the processes this launcher started
+                except OSError:
+                    pass
+        deadline = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, 9)
+                except OSError:
+                    pass
+                p.wait()
         return 1
-    sys.stdout.write(out.decode())
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
     return 0
 
@@ -225,7 +279,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        import datetime
+
+        # nccl == RCCL on ROCm; a short timeout: a missing rank must become an error, not a hang
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("POINTOPS_BENCH_PG_TIMEOUT_S", "300"))))
 
     from pytorch3d_pointops_amd import _C
     from pytorch3d_pointops_amd.sharded import shard_bounds

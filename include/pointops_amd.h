@@ -165,6 +165,25 @@ int pointops_gather_neighbors_backward(const float* grad_out, const int64_t* idx
                                        void* stream);
 
 /*
+ * DETERMINISTIC forms of the two scatter backward passes (csrc/backward_det.hip): the neighbour table is inverted
+ * with a stable radix sort and every target row sums its addends in table order -- for knn_points_backward the order
+ * of the reference's CPU loop (csrc/knn/knn_cpu.cpp:100-125), so grad_p2 is bit-equal to it.  Same arguments and
+ * masks as the calls above plus `workspace` of pointops_backward_det_workspace_bytes(N, L, K, M) bytes
+ * (knn: L = P1, M = P2; gather: L, M as given).  The neighbour table must have fewer than 2^31 entries.
+ * The host wrappers select them under torch.use_deterministic_algorithms(True).
+ */
+size_t pointops_backward_det_workspace_bytes(int64_t N, int64_t L, int64_t K, int64_t M);
+int pointops_knn_points_backward_det(const float* p1, const float* p2, const int64_t* lengths1,
+                                     const int64_t* lengths2, const int64_t* idxs,
+                                     const float* grad_dists, int64_t N, int64_t P1, int64_t P2,
+                                     int64_t D, int64_t K, int norm, float* grad_p1, float* grad_p2,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+int pointops_gather_neighbors_backward_det(const float* grad_out, const int64_t* idx,
+                                           const int64_t* lengths, int64_t N, int64_t M, int64_t U,
+                                           int64_t L, int64_t K, float* grad_x, void* workspace,
+                                           size_t workspace_bytes, void* stream);
+
+/*
  * Chamfer point-loss reduction -- the fused tail of
  * `_chamfer_distance_single_direction` (reference: functions/chamfer.py:134-185)
  * for point_reduction in {"sum","mean"}:

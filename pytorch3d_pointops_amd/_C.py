@@ -48,6 +48,10 @@ _SIGNATURES = {
     "pointops_gather_neighbors": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "pointops_gather_neighbors_backward": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp,
                                                   _vp]),
+    "pointops_backward_det_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "pointops_knn_points_backward_det": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp,
+                                                _vp, _vp, _sz, _vp]),
+    "pointops_gather_neighbors_backward_det": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "pointops_chamfer_reduce": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),
     "pointops_sample_pdf": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp]),
     "pointops_point_covariances": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
@@ -175,7 +179,7 @@ def knn_grid_fallback_counts(p1, p2, lengths1, lengths2, norm: int, K: int):
     N, P1, D = p1.shape
     P2 = p2.shape[1]
     if not knn_check_version(3, D, K):
-        raise RuntimeError("grid family needs D <= 3 and K <= 32")
+        raise RuntimeError("grid family needs D <= 3 and K <= 64")
     with torch.cuda.device(dev):
         idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
         dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
@@ -224,21 +228,39 @@ def knn_check_version(version: int, D: int, K: int) -> bool:
 
 
 # reference: csrc/knn/knn.h:127-149
-def knn_points_backward(p1, p2, lengths1, lengths2, idxs, norm: int, grad_dists):
+def knn_points_backward(p1, p2, lengths1, lengths2, idxs, norm: int, grad_dists, deterministic: bool = False):
+    """`deterministic`: grad_p2 through the inverted neighbour table (csrc/backward_det.hip) -- reproducible and
+    bit-equal to the reference's CPU kernel -- instead of fp32 scatter-adds (LDS tiles / device atomics)."""
     dev = _require_gpu(p1, p2, lengths1, lengths2, idxs, grad_dists)
     if p1.dtype != torch.float32 or p2.dtype != torch.float32 or grad_dists.dtype != torch.float32:
         raise RuntimeError("expected scalar type Float")
     p1, p2 = p1.contiguous(), p2.contiguous()
-    lengths1, lengths2 = lengths1.contiguous(), lengths2.contiguous()
-    idxs, grad_dists = idxs.contiguous(), grad_dists.contiguous()
+    # the kernels read int64 through raw pointers: any other integer type would be read past its buffer (the
+    # reference's accessor<int64_t, 1> raises: knn_cpu.cpp:84-88)
+    lengths1, lengths2 = _i64c(lengths1, "lengths1"), _i64c(lengths2, "lengths2")
+    idxs, grad_dists = _i64c(idxs, "idxs"), grad_dists.contiguous()
+    if p1.dim() != 3 or p2.dim() != 3 or idxs.dim() != 3:
+        raise RuntimeError("knn_points_backward: p1, p2 and idxs must be 3-dimensional")
     N, P1, D = p1.shape
     P2 = p2.shape[1]
     K = idxs.shape[2]
-    if idxs.shape != (N, P1, K) or grad_dists.shape != (N, P1, K):
+    if (p2.shape[0] != N or p2.shape[2] != D or idxs.shape != (N, P1, K) or grad_dists.shape != (N, P1, K)
+            or lengths1.shape != (N,) or lengths2.shape != (N,)):
         raise RuntimeError("knn_points_backward: inconsistent shapes")
     with torch.cuda.device(dev):
         grad_p1 = torch.empty((N, P1, D), dtype=torch.float32, device=dev)
         grad_p2 = torch.empty((N, P2, D), dtype=torch.float32, device=dev)
+        if deterministic:
+            ws_bytes = _lib.pointops_backward_det_workspace_bytes(N, P1, K, P2)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            _check(
+                _lib.pointops_knn_points_backward_det(p1.data_ptr(), p2.data_ptr(), lengths1.data_ptr(),
+                                                      lengths2.data_ptr(), idxs.data_ptr(), grad_dists.data_ptr(),
+                                                      N, P1, P2, D, K, int(norm), grad_p1.data_ptr(),
+                                                      grad_p2.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
+                "knn_points_backward(deterministic)",
+            )
+            return grad_p1, grad_p2
         _check(
             _lib.pointops_knn_points_backward(p1.data_ptr(), p2.data_ptr(), lengths1.data_ptr(),
                                               lengths2.data_ptr(), idxs.data_ptr(),
@@ -255,9 +277,16 @@ def ball_query(p1, p2, lengths1, lengths2, K: int, radius: float):
     if p1.dtype != torch.float32 or p2.dtype != torch.float32:
         raise RuntimeError("expected scalar type Float for p1/p2")
     p1, p2 = p1.contiguous(), p2.contiguous()  # ball_query.h:74-77
-    lengths1, lengths2 = lengths1.contiguous(), lengths2.contiguous()
+    lengths1, lengths2 = _i64c(lengths1, "lengths1"), _i64c(lengths2, "lengths2")  # (accessor<int64_t, 1> in the reference)
+    if p1.dim() != 3 or p2.dim() != 3:
+        raise RuntimeError("ball_query: p1 and p2 must be 3-dimensional")
     N, P1, D = p1.shape
     P2 = p2.shape[1]
+    if p2.shape[0] != N or p2.shape[2] != D or lengths1.shape != (N,) or lengths2.shape != (N,):
+        raise RuntimeError("ball_query: inconsistent shapes")
+    K = int(K)
+    if K < 0:
+        raise RuntimeError("ball_query: K must be non-negative")
     with torch.cuda.device(dev):
         idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
         dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
@@ -279,7 +308,10 @@ def sample_farthest_points(points, lengths, K, start_idxs):
     if points.dtype != torch.float32:
         raise RuntimeError("expected scalar type Float for points")
     points = points.contiguous()
-    lengths, K, start_idxs = lengths.contiguous(), K.contiguous(), start_idxs.contiguous()
+    # int64 through raw pointers (the reference's accessor<int64_t, 1>: sample_farthest_points_cpu.cpp:33-36)
+    lengths, K, start_idxs = _i64c(lengths, "lengths"), _i64c(K, "K"), _i64c(start_idxs, "start_idxs")
+    if points.dim() != 3:
+        raise RuntimeError("sample_farthest_points: points must be 3-dimensional")
     N, P, D = points.shape
     if lengths.shape != (N,) or K.shape != (N,) or start_idxs.shape != (N,):
         raise RuntimeError("sample_farthest_points: lengths, K and start_idxs must have shape (N,)")
@@ -400,13 +432,23 @@ def gather_neighbors(x, idx, lengths=None):
     return out
 
 
-def gather_neighbors_backward(grad_out, idx, lengths, M: int):
+def gather_neighbors_backward(grad_out, idx, lengths, M: int, deterministic: bool = False):
     dev = _require_gpu(grad_out, idx) if lengths is None else _require_gpu(grad_out, idx, lengths)
     grad_out, idx = _f32c(grad_out, "grad_out"), _i64c(idx, "idx")
     lengths = _i64c(lengths, "lengths") if lengths is not None else None
     N, L, K, U = grad_out.shape
     with torch.cuda.device(dev):
         grad_x = torch.empty((N, M, U), dtype=torch.float32, device=dev)
+        if deterministic:  # inverted neighbour table: every row of x sums its addends in table order
+            ws_bytes = _lib.pointops_backward_det_workspace_bytes(N, L, K, M)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            _check(
+                _lib.pointops_gather_neighbors_backward_det(
+                    grad_out.data_ptr(), idx.data_ptr(), lengths.data_ptr() if lengths is not None else None,
+                    N, M, U, L, K, grad_x.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
+                "gather_neighbors_backward(deterministic)",
+            )
+            return grad_x
         _check(
             _lib.pointops_gather_neighbors_backward(
                 grad_out.data_ptr(), idx.data_ptr(),

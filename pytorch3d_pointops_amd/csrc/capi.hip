@@ -15,10 +15,19 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// value of `key` inside POINTOPS_DEBUG="k=v,k=v": pointer to v (terminated by ',' or NUL), or nullptr
+// value of `key` inside POINTOPS_DEBUG="k=v,k=v": pointer to v (terminated by ',' or NUL), or nullptr.
+// The common case -- the variable is not set -- costs one getenv and nothing else; a set variable is copied once
+// and re-copied only when its text changes (tests flip it between calls), so look-ups never parse the environment
+// block beyond that one getenv.
 static const char* debug_value(const char* key) {
   const char* e = getenv("POINTOPS_DEBUG");
-  if (!e) return nullptr;
+  if (!e || !*e) return nullptr;
+  static thread_local char cached[512] = "";
+  if (strncmp(cached, e, sizeof(cached) - 1) != 0) {
+    strncpy(cached, e, sizeof(cached) - 1);
+    cached[sizeof(cached) - 1] = 0;
+  }
+  e = cached;
   const size_t kl = strlen(key);
   while (*e) {
     const char* end = strchr(e, ',');

@@ -13,6 +13,15 @@
 // Per iteration: update + per-lane argmax (strict > keeps the lowest index),
 // wave argmax by xor-butterfly on (value, index) keys preferring the LOWER index on
 // ties, one LDS exchange across the 16 waves, broadcast of the winner.
+//
+// MEMORY-MODEL NOTE on the cluster kernel's fastest exchange (fps_mode 2, the default where it verifies): members of
+// a cloud publish their candidate with WORKGROUP-scope stores that OTHER workgroups poll with L1-bypassing loads.
+// That hand-off is not promised by the HIP memory model; it works because gfx950's vector L1 is write-through and
+// all members of a verified cloud share one XCD's L2.  It is therefore never trusted for correctness: a cloud only
+// uses it after its members have proven (through the agent-scope protocol, row 0) that they run on one XCD, every
+// spin is bounded, and a cloud whose exchange times out is flagged and recomputed by the single-workgroup kernel
+// (tests force that with fps_spin_limit=0).  On another chip the guard would route every cloud to the agent-scope
+// exchange or the repair pass -- slower, still exact.
 #include <float.h>
 
 #include "common.h"
@@ -385,15 +394,17 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
 using namespace pointops;
 
 static int fps_num_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
+  // per DEVICE (a process may drive several GPUs; round 2 remembered the first device's count for all of them)
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cus[dev] == 0) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 64;
+    int c = 0;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
+    cus[dev] = c > 0 ? c : 64;
   }
-  return cus;
+  return cus[dev];
 }
 
 // cluster geometry of the register-resident kernel: points per lane and workgroups per cloud

@@ -204,6 +204,8 @@ class _chamfer_pair(Function):
 def _fused_direction_ok(x, y, x_features, y_features, feature_names, return_features, point_reduction):
     if point_reduction not in ("sum", "mean") or torch.compiler.is_compiling():
         return False  # (traced graphs take the composed path over the registered ops)
+    if torch.are_deterministic_algorithms_enabled():
+        return False  # the fused backward scatters with fp32 atomics; the composed path has deterministic backward passes
     if not (x.is_cuda and y.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32):
         return False
     if return_features:

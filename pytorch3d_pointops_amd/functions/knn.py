@@ -11,7 +11,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
-from ._common import alert_not_deterministic, as_f32, full_lengths, neighbor_backward, point_pair
+from ._common import deterministic_requested, as_f32, full_lengths, neighbor_backward, point_pair
 
 _KNN = namedtuple("KNN", "dists idx knn")
 
@@ -91,9 +91,10 @@ class _gather_neighbors(Function):
     @once_differentiable
     def backward(ctx, grad_out):
         idx, lengths = ctx.saved_tensors
-        alert_not_deterministic("knn_gather backward")  # fp32 scatter-add (LDS or device atomics)
+        # fp32 scatter-add (LDS or device atomics); the inverted-table form when determinism is requested
         grad_x = _C.gather_neighbors_backward(as_f32(grad_out).contiguous(), idx,
-                                              lengths if ctx.has_lengths else None, ctx.M)
+                                              lengths if ctx.has_lengths else None, ctx.M,
+                                              deterministic=deterministic_requested())
         return grad_x, None, None
 
 

@@ -9,26 +9,22 @@ from typing import List, Optional, Tuple, Union
 import torch
 
 from .. import _C
+from ._common import as_f32, batch_vector, full_lengths, lengths_max
 from .utils import masked_gather
 
 
-def _prepare(points, lengths, K, too_large_msg):
-    N, P, D = points.shape
-    device = points.device
+def _per_cloud(points, lengths, K, too_large_msg):
+    """(lengths, K) as (N,) int64 device vectors, checked the way the reference checks them (:55-70, :131-146)."""
+    n, p, _ = points.shape
     if lengths is None:
-        lengths = torch.full((N,), P, dtype=torch.int64, device=device)
+        lengths = full_lengths(n, p, points.device)
     else:
-        if lengths.shape != (N,):
+        if lengths.shape != (n,):
             raise ValueError("points and lengths must have same batch dimension.")
-        if lengths.max() > P:
+        if lengths_max(lengths) > p:
             raise ValueError(too_large_msg)
-    if isinstance(K, int):
-        K = torch.full((N,), K, dtype=torch.int64, device=device)
-    elif isinstance(K, list):
-        K = torch.tensor(K, dtype=torch.int64, device=device)
-    if K.shape[0] != N:
-        raise ValueError("K and points must have the same batch dimension")
-    return lengths, K
+        lengths = batch_vector(lengths, n, points.device, "lengths", "points and lengths must have same batch dimension.")
+    return lengths, batch_vector(K, n, points.device, "K", "K and points must have the same batch dimension")
 
 
 def sample_farthest_points(
@@ -44,21 +40,11 @@ def sample_farthest_points(
     are -1 and points 0.0 beyond ``min(lengths[n], K[n])``.  Indices are computed
     without autograd; the points come from a differentiable gather.
     """
-    lengths, K = _prepare(points, lengths, K, "A value in lengths was too large.")
-    N = points.shape[0]
-
-    if not (points.dtype == torch.float32):
-        points = points.to(torch.float32)
-    if not (lengths.dtype == torch.int64):
-        lengths = lengths.to(torch.int64)
-    if not (K.dtype == torch.int64):
-        K = K.to(torch.int64)
-    K = K.to(points.device)
-
+    lengths, K = _per_cloud(points, lengths, K, "A value in lengths was too large.")
+    points = as_f32(points)
     start_idxs = torch.zeros_like(lengths)
-    if random_start_point:
-        # same RNG consumption as the reference (:86-89): one torch.randint per cloud
-        for n in range(N):
+    if random_start_point:  # one torch.randint draw per cloud, the reference's RNG consumption (:86-89)
+        for n in range(points.shape[0]):
             start_idxs[n] = torch.randint(high=lengths[n], size=(1,)).item()
 
     with torch.no_grad():
@@ -81,7 +67,7 @@ def sample_farthest_points_naive(
     Kept as the readable cross-check the reference's examples use
     (examples/fps_on_pointclouds.py:122-155); it is not the product path.
     """
-    lengths, K = _prepare(points, lengths, K, "Invalid lengths.")
+    lengths, K = _per_cloud(points, lengths, K, "Invalid lengths.")
     N, P, D = points.shape
     device = points.device
     max_K = int(torch.max(K))

@@ -42,7 +42,8 @@ def _(p1, p2, lengths1, lengths2, norm, K, version):
 @_op(f"{NS}::knn_points_backward", mutates_args=())
 def knn_points_backward(p1: Tensor, p2: Tensor, lengths1: Tensor, lengths2: Tensor, idxs: Tensor, norm: int,
                         grad_dists: Tensor) -> Tuple[Tensor, Tensor]:
-    return _C.knn_points_backward(p1, p2, lengths1, lengths2, idxs, norm, grad_dists)
+    return _C.knn_points_backward(p1, p2, lengths1, lengths2, idxs, norm, grad_dists,
+                                  deterministic=torch.are_deterministic_algorithms_enabled())
 
 
 @knn_points_backward.register_fake
@@ -150,7 +151,8 @@ def _(x, idx, lengths):
 
 @_op(f"{NS}::gather_neighbors_backward", mutates_args=())
 def gather_neighbors_backward(grad_out: Tensor, idx: Tensor, lengths: Optional[Tensor], M: int) -> Tensor:
-    return _C.gather_neighbors_backward(grad_out, idx, lengths, M)
+    return _C.gather_neighbors_backward(grad_out, idx, lengths, M,
+                                        deterministic=torch.are_deterministic_algorithms_enabled())
 
 
 @gather_neighbors_backward.register_fake

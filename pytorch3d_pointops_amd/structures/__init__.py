@@ -1,3 +1,5 @@
-from .pointclouds import Pointclouds, join_pointclouds_as_batch
+from .pointclouds import (Pointclouds, all_close, get_bounding_boxes, join_pointclouds_as_batch,
+                          join_pointclouds_as_scene, offset, scale, subsample)
 
-__all__ = ["Pointclouds", "join_pointclouds_as_batch"]
+__all__ = ["Pointclouds", "all_close", "get_bounding_boxes", "join_pointclouds_as_batch", "join_pointclouds_as_scene",
+           "offset", "scale", "subsample"]

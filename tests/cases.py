@@ -206,3 +206,54 @@ def example_clouds():
     n1 = unit(p1 / np.array([2.25, 0.64, 1.0]))
     return dict(points=[p0, p1], normals=[unit(p0), n1],
                 colors=[synth.uniform_f32(903, (1500, 3)), synth.uniform_f32(904, (800, 3))])
+
+
+def example2_inputs():
+    """Inputs shaped like the reference's other self-checking example scripts (ball_query_on_pointclouds.py:20-47,
+    fps_on_pointclouds.py:22-64, chamfer_loss.py:17-28, packed_to_padded_on_pointclouds.py:22-64,
+    utils_on_pointclouds.py:23-66): the scripts draw from torch.rand / randn; here the same shapes and value ranges come
+    from the seeded generator (make_golden.py stores nothing but outputs; these arrays are regenerated by the tests)."""
+    def u(seed, shape):
+        return synth.uniform_f32(seed, shape).astype(np.float64)
+
+    def shell(seed, n, r0, r1, s=(1.0, 1.0, 1.0)):
+        a = u(seed, (n, 3))
+        theta, phi, r = a[:, 0] * 2 * np.pi, a[:, 1] * np.pi, a[:, 2] * (r1 - r0) + r0
+        return np.stack([r * np.sin(phi) * np.cos(theta) * s[0], r * np.sin(phi) * np.sin(theta) * s[1],
+                         r * np.cos(phi) * s[2]], axis=1).astype(np.float32)
+
+    def normalish(seed, shape, scale=1.0):  # sum of 4 uniforms, centred: bell-shaped like randn, fully reproducible
+        a = u(seed, shape + (4,)).sum(-1) - 2.0
+        return (a * (scale * 1.7320508)).astype(np.float32)
+
+    def cylinder(seed, n, rmax):
+        a = u(seed, (n, 3))
+        theta, r, z = a[:, 0] * 2 * np.pi, a[:, 1] * rmax, a[:, 2] * 2 - 1
+        return np.stack([r * np.cos(theta), r * np.sin(theta), z], axis=1).astype(np.float32)
+
+    lin = np.linspace(-1, 1, 10, dtype=np.float32)
+    gx, gy, gz = np.meshgrid(lin, lin, lin, indexing="ij")
+    th = np.linspace(0, 2 * np.pi, 150, dtype=np.float32)
+    circles = np.stack([np.concatenate([0.8 * np.cos(th), 0.4 * np.cos(th)]),
+                        np.concatenate([0.8 * np.sin(th), 0.4 * np.sin(th)])], axis=1).astype(np.float32)
+    sizes = [50, 100, 5000, 10, 1000, 20, 3000]
+    return dict(
+        ball=dict(points=[shell(3101, 2000, 0.5, 1.0), (u(3102, (500, 3)) * 4 - 2).astype(np.float32)],
+                  lattice=np.stack([gx.ravel(), gy.ravel(), gz.ravel()], axis=1).astype(np.float32)),
+        fps=dict(points=[shell(3111, 1000, 0.5, 1.0), (u(3112, (800, 3)) * 2 - 1).astype(np.float32),
+                         cylinder(3113, 1200, 1.0)],
+                 colors0=synth.uniform_f32(3114, (1000, 3)), single=(u(3115, (500, 3)) * 2 - 1).astype(np.float32),
+                 compare=synth.uniform_f32(3116, (1, 2000, 3)), circles=circles),
+        chamfer=dict(p1=normalish(3121, (2, 100, 3)), p2=normalish(3122, (2, 120, 3)),
+                     n1=normalish(3123, (2, 100, 3)), n2=normalish(3124, (2, 120, 3)),
+                     c1=normalish(3125, (2, 100, 3)), c2=normalish(3126, (2, 120, 3))),
+        packed=dict(points=[normalish(3131, (100, 3), 0.5), cylinder(3132, 500, 2.0), normalish(3133, (2000, 3), 1.5),
+                            normalish(3134, (25, 3), 0.2)],
+                    intensities=[synth.uniform_f32(3135 + i, (n, 1)) for i, n in enumerate((100, 500, 2000, 25))],
+                    var_points=[normalish(3141 + i, (n, 3)) for i, n in enumerate(sizes)],
+                    var_features=[normalish(3151 + i, (n, 16)) for i, n in enumerate(sizes)]),
+        utils=dict(points=[shell(3161, 1000, 0.2, 1.0), shell(3162, 800, 0.4, 1.0, (4.0, 0.5, 1.0))],
+                   weights=[(u(3163, (1000, 1)) * 0.5 + 0.5).astype(np.float32),
+                            (u(3164, (800, 1)) * 0.8 + 0.2).astype(np.float32)],
+                   values=[normalish(3165, (1000, 4)), normalish(3166, (800, 4))]),
+    )

@@ -291,6 +291,149 @@ def gen_examples():
     save("examples", **out)
 
 
+def gen_examples2():
+    """The call patterns of the reference's other self-checking example scripts at their own sizes (inputs:
+    cases.example2_inputs(), regenerated by the tests):
+      examples/ball_query_on_pointclouds.py:50-125   self ball query of a Pointclouds batch (K=50, r=0.3, return_nn)
+                                                     and a 10x10x10 lattice (K=30, r=0.25) next to knn_points K=10
+      examples/fps_on_pointclouds.py:66-215          single cloud / ragged batch with per-cloud K and random starts
+                                                     (torch.manual_seed before each call), optimized vs naive, 2-D
+      examples/chamfer_loss.py:13-89                 tensors with two feature sets, Pointclouds inputs, single direction
+      examples/packed_to_padded_on_pointclouds.py:67-124   packed <-> padded round trips of points and features
+      examples/utils_on_pointclouds.py:69-237        get_point_covariances K=16, wmean, knn_points K=8 + masked_gather
+    Bit-exact outputs larger than a few KB are stored as sha256 digests plus every 37th row."""
+    from pytorch3d_pointops.functions.utils import get_point_covariances, wmean
+    from pytorch3d_pointops.structures import Pointclouds as RefPointclouds
+
+    inp = cases.example2_inputs()
+    out, meta = {}, {}
+
+    def put(tag, t, exact=True):
+        a = t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        if a.dtype == np.int64:
+            a = a.astype(np.int32)
+        if exact and a.nbytes > 8192:
+            meta[tag] = dict(sha256=hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest(),
+                             shape=list(a.shape), dtype=str(a.dtype))
+            flat = a.reshape(-1, a.shape[-1]) if a.ndim > 1 else a
+            out[tag + "/rows"] = flat[::37]
+        else:
+            out[tag] = a
+
+    # ---- ball query
+    b = inp["ball"]
+    pc = RefPointclouds(points=[T(a) for a in b["points"]])
+    pad, lens = pc.points_padded(), pc.num_points_per_cloud()
+    r = ball_query(p1=pad, p2=pad, lengths1=lens, lengths2=lens, K=50, radius=0.3, return_nn=True)
+    put("ball/dists", r.dists), put("ball/idx", r.idx), put("ball/knn", r.knn)
+    lat = T(b["lattice"])[None]
+    r = ball_query(p1=lat, p2=lat, K=30, radius=0.25, return_nn=False)
+    k = knn_points(p1=lat, p2=lat, K=10, return_nn=False)
+    put("lattice/ball_dists", r.dists), put("lattice/ball_idx", r.idx)
+    put("lattice/knn_dists", k.dists), put("lattice/knn_idx", k.idx)
+    # ---- FPS
+    f = inp["fps"]
+    torch.manual_seed(123)
+    sp, si = sample_farthest_points(T(f["single"])[None], K=50, random_start_point=True)
+    put("fps/single_idx", si), put("fps/single_points", sp)
+    pc = RefPointclouds(points=[T(a) for a in f["points"]])
+    torch.manual_seed(42)
+    sp, si = sample_farthest_points(pc.points_padded(), lengths=pc.num_points_per_cloud(), K=[100, 80, 150],
+                                    random_start_point=True)
+    put("fps/batch_idx", si), put("fps/batch_points", sp)
+    so, io = sample_farthest_points(T(f["compare"]), K=200, random_start_point=False)
+    sn, in_ = sample_farthest_points_naive(T(f["compare"]), K=200, random_start_point=False)
+    assert torch.equal(io, in_)
+    put("fps/compare_idx", io)
+    torch.manual_seed(7)
+    sp, si = sample_farthest_points(T(f["points"][0])[None], K=100, random_start_point=True)
+    put("fps/colors_idx", si), put("fps/colors", masked_gather(T(f["colors0"])[None], si))
+    sn, in_ = sample_farthest_points_naive(T(f["circles"])[None], K=50, random_start_point=False)
+    put("fps/circles_idx", in_)
+    # ---- chamfer
+    c = {k: T(v) for k, v in inp["chamfer"].items()}
+    l, lf = chamfer_distance(c["p1"], c["p2"], x_features={"normals": c["n1"], "colors": c["c1"]},
+                             y_features={"normals": c["n2"], "colors": c["c2"]}, feature_names=["normals", "colors"])
+    out["chamfer/tensor"] = np.array([float(l), float(lf["normals"]), float(lf["colors"])], np.float64)
+    pc1 = RefPointclouds(points=list(c["p1"]), features={"normals": list(c["n1"]), "colors": list(c["c1"])})
+    pc2 = RefPointclouds(points=list(c["p2"]), features={"normals": list(c["n2"]), "colors": list(c["c2"])})
+    l, lf = chamfer_distance(pc1, pc2, feature_names=["normals", "colors"])
+    out["chamfer/pointclouds"] = np.array([float(l), float(lf["normals"]), float(lf["colors"])], np.float64)
+    l, lf = chamfer_distance(pc1, pc2, feature_names=["normals"], single_directional=True)
+    out["chamfer/single"] = np.array([float(l), float(lf["normals"])], np.float64)
+    # ---- packed <-> padded
+    k = inp["packed"]
+    pc = RefPointclouds(points=[T(a) for a in k["points"]], features={"intensities": [T(a) for a in k["intensities"]]})
+    lens = pc.num_points_per_cloud()
+    first = torch.cat([torch.tensor([0]), lens.cumsum(0)[:-1]])
+    pp, ip = pc.points_packed(), pc.get_features_packed("intensities")
+    pad, ipad = packed_to_padded(pp, first, int(lens.max())), packed_to_padded(ip, first, int(lens.max()))
+    put("packed/points_packed", pp), put("packed/points_padded", pad), put("packed/intensities_padded", ipad)
+    put("packed/points_repacked", padded_to_packed(pad, first, int(lens.sum())))
+    put("packed/intensities_repacked", padded_to_packed(ipad, first, int(lens.sum())))
+    pc = RefPointclouds(points=[T(a) for a in k["var_points"]], features={"features": [T(a) for a in k["var_features"]]})
+    lens = pc.num_points_per_cloud()
+    first = torch.cat([torch.tensor([0]), lens.cumsum(0)[:-1]])
+    fpad = packed_to_padded(pc.get_features_packed("features"), first, int(lens.max()))
+    put("packed/var_features_padded", fpad)
+    put("packed/var_features_repacked", padded_to_packed(fpad, first, int(lens.sum())))
+    # ---- utils
+    u = inp["utils"]
+    pc = RefPointclouds(points=[T(a) for a in u["points"]])
+    cov, nn = get_point_covariances(pc.points_padded(), pc.num_points_per_cloud(), 16)
+    out["utils/cov"] = cov.numpy()[:, ::5]
+    put("utils/cov_knn", nn)
+    out["utils/wmean"] = np.stack([wmean(T(p), T(w).squeeze(), dim=0, keepdim=False).numpy()
+                                   for p, w in zip(u["points"], u["weights"])])
+    kn = knn_points(T(u["points"][0])[None], T(u["points"][0])[None], K=8, return_nn=False)
+    put("utils/knn_idx", kn.idx), put("utils/gathered_values", masked_gather(T(u["values"][0])[None], kn.idx))
+    save("examples2", **out)
+    with open(os.path.join(HERE, "examples2_meta.json"), "w") as fh:
+        json.dump(meta, fh, indent=1, sort_keys=True)
+    print("wrote examples2_meta.json")
+
+
+def gen_pointclouds():
+    """The container calls of examples/pointclouds.py:12-174 (construction with named features, the three views, one
+    cloud, update_padded with and without new features) plus the module-level helpers its callers use (offset, scale,
+    bounding boxes, scene join, inside_box, extend, split) through the REFERENCE's Pointclouds: host-side bookkeeping,
+    so the fixture is checked on the CPU (tests/test_boundary_cpu.py)."""
+    from pytorch3d_pointops.structures import point_structure as ps
+
+    inp = cases.example_clouds()
+    pc = ps.Pointclouds(points=[T(a) for a in inp["points"]],
+                        features={"normals": [T(a) for a in inp["normals"]], "colors": [T(a) for a in inp["colors"]]})
+    out = {"padded": pc.points_padded().numpy(), "packed": pc.points_packed().numpy(),
+           "normals_padded": pc.get_features_padded("normals").numpy(),
+           "colors_packed": pc.get_features_packed("colors").numpy(),
+           "first_idx": pc.cloud_to_packed_first_idx().numpy(), "packed_to_cloud": pc.packed_to_cloud_idx().numpy(),
+           "padded_to_packed": pc.padded_to_packed_idx().numpy()}
+    pts, feats = pc.get_cloud(1)
+    out["cloud1_points"], out["cloud1_colors"] = pts.numpy(), feats["colors"].numpy()
+    new_pts = pc.points_padded() * 2.0 + 1.0
+    up = pc.update_padded(new_pts)
+    out["update_packed"], out["update_normals_packed"] = up.points_packed().numpy(), up.get_features_packed("normals").numpy()
+    up2 = pc.update_padded(new_pts, new_features_padded={"normals": pc.get_features_padded("normals") * -1.0})
+    out["update2_normals_list1"] = up2.get_features_list("normals")[1].numpy()
+    out["update2_names"] = np.array(sorted(up2.features_list().keys()))
+    off = ps.offset(pc, torch.tensor([0.5, -1.0, 2.0]))
+    out["offset_padded"] = off.points_padded().numpy()
+    sc = ps.scale(pc, torch.tensor([2.0, 0.25]))
+    out["scale_packed"], out["scale_padded"] = sc.points_packed().numpy(), sc.points_padded().numpy()
+    out["bboxes"] = ps.get_bounding_boxes(pc).numpy()
+    scene = ps.join_pointclouds_as_scene(pc)
+    out["scene_padded"], out["scene_colors"] = scene.points_padded().numpy(), scene.get_features_padded("colors").numpy()
+    box = torch.tensor([[[-0.5, -0.5, -0.5], [0.5, 0.5, 0.5]], [[0.0, -1.0, -1.0], [2.0, 1.0, 1.0]]])
+    out["inside_box"] = pc.inside_box(box).numpy()
+    ext = pc.extend(2)
+    out["extend_lengths"] = ext.num_points_per_cloud().numpy()
+    out["extend_padded"] = ext.points_padded().numpy()
+    parts = ext.split([1, 3])
+    out["split1_lengths"] = parts[1].num_points_per_cloud().numpy()
+    out["split1_normals_packed"] = parts[1].get_features_packed("normals").numpy()
+    save("pointclouds_api", **out)
+
+
 def gen_big():
     """cfg2-size single clouds: digests + sampled rows (the full idx would be 8 MB per cloud)."""
     meta = {}
@@ -343,5 +486,7 @@ if __name__ == "__main__":
     gen_sample_pdf()
     gen_covariances()
     gen_examples()
+    gen_examples2()
+    gen_pointclouds()
     if "--big" in sys.argv:
         gen_big()

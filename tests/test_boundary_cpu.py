@@ -159,3 +159,72 @@ def test_lengths_validation_cache_follows_the_tensor():
     with pytest.raises(ValueError, match="too long"):
         _handle_pointcloud_input(x, lengths, None)
     assert lengths_max(torch.tensor([1, 2])) == 2 and lengths_max(torch.zeros(0, dtype=torch.int64)) == 0
+    # The documented caveat: a write that bypasses the version counter is not seen (the kernels clamp lengths to the
+    # padded size, so a stale maximum can only lose the "too long" error, never read out of bounds) ...
+    quiet = torch.tensor([5, 4])
+    assert lengths_max(quiet) == 5
+    quiet.data[1] = 9
+    assert quiet._version == 0 and lengths_max(quiet) == 5
+    quiet += 0  # ... until any in-place op on the tensor itself moves the counter
+    assert lengths_max(quiet) == 9
+    # entries die with their tensors (weakref finalizer), the table does not grow with dead ids
+    from pytorch3d_pointops_amd.functions import _common
+    import gc
+
+    before = len(_common._MAX_CACHE)
+    for _ in range(50):
+        lengths_max(torch.tensor([3, 1]))
+    gc.collect()
+    assert len(_common._MAX_CACHE) <= before + 1
+
+
+def test_pointclouds_container_against_reference_fixture():
+    """The container calls of the reference's examples/pointclouds.py:12-174 and the module-level helpers its callers
+    use (update_padded, offset, scale, get_bounding_boxes, join_pointclouds_as_scene, inside_box, extend, split,
+    subsample, all_close) on this package's Pointclouds against what the REFERENCE's container returned for the same
+    inputs (tests/golden/pointclouds_api.npz, make_golden.py gen_pointclouds)."""
+    import numpy as np
+
+    import cases
+    from conftest import load_golden
+    from pytorch3d_pointops_amd import structures as st
+
+    g = load_golden("pointclouds_api")
+    inp = cases.example_clouds()
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    pc = st.Pointclouds(points=[T(a) for a in inp["points"]],
+                        features={"normals": [T(a) for a in inp["normals"]], "colors": [T(a) for a in inp["colors"]]})
+    eq = lambda t, name: np.array_equal(t.numpy(), g[name])  # noqa: E731
+    assert eq(pc.points_padded(), "padded") and eq(pc.points_packed(), "packed")
+    assert eq(pc.get_features_padded("normals"), "normals_padded") and eq(pc.get_features_packed("colors"), "colors_packed")
+    assert eq(pc.cloud_to_packed_first_idx(), "first_idx") and eq(pc.packed_to_cloud_idx(), "packed_to_cloud")
+    assert eq(pc.padded_to_packed_idx(), "padded_to_packed")
+    assert pc.get_features_list("nope") is None and pc.get_features_packed("nope") is None
+    pts, feats = pc.get_cloud(1)
+    assert eq(pts, "cloud1_points") and eq(feats["colors"], "cloud1_colors") and sorted(feats) == ["colors", "normals"]
+    new_pts = pc.points_padded() * 2.0 + 1.0
+    up = pc.update_padded(new_pts)
+    assert eq(up.points_packed(), "update_packed") and eq(up.get_features_packed("normals"), "update_normals_packed")
+    up2 = pc.update_padded(new_pts, new_features_padded={"normals": pc.get_features_padded("normals") * -1.0})
+    assert eq(up2.get_features_list("normals")[1], "update2_normals_list1")
+    assert sorted(up2.features_list().keys()) == list(g["update2_names"])
+    with pytest.raises(ValueError, match="same number of points"):
+        pc.update_padded(new_pts[:, :-1])
+    assert eq(st.offset(pc, torch.tensor([0.5, -1.0, 2.0])).points_padded(), "offset_padded")
+    sc = st.scale(pc, torch.tensor([2.0, 0.25]))
+    assert eq(sc.points_packed(), "scale_packed") and eq(sc.points_padded(), "scale_padded")
+    assert eq(pc.points_padded(), "padded")  # (out of place: the original is untouched)
+    assert eq(st.get_bounding_boxes(pc), "bboxes")
+    scene = st.join_pointclouds_as_scene(pc)
+    assert eq(scene.points_padded(), "scene_padded") and eq(scene.get_features_padded("colors"), "scene_colors")
+    box = torch.tensor([[[-0.5, -0.5, -0.5], [0.5, 0.5, 0.5]], [[0.0, -1.0, -1.0], [2.0, 1.0, 1.0]]])
+    assert eq(pc.inside_box(box), "inside_box")
+    ext = pc.extend(2)
+    assert eq(ext.num_points_per_cloud(), "extend_lengths") and eq(ext.points_padded(), "extend_padded")
+    parts = ext.split([1, 3])
+    assert eq(parts[1].num_points_per_cloud(), "split1_lengths")
+    assert eq(parts[1].get_features_packed("normals"), "split1_normals_packed")
+    sub = st.subsample(pc, [100, 5000])
+    assert sub.num_points_per_cloud().tolist() == [100, 800] and sub.get_features_list("colors")[0].shape == (100, 3)
+    assert st.subsample(pc, 5000) is pc
+    assert st.all_close(pc, pc.clone()) and not st.all_close(pc, sc)

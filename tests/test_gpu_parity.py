@@ -1045,31 +1045,76 @@ def test_registered_ops_and_torch_compile(dev):
     assert torch.equal(idx, e[1]) and torch.equal(a3.grad, torch.autograd.grad(fn(a1, b1, f1)[0].sum(), a1)[0])
 
 
-def test_deterministic_algorithms_alert(dev):
-    """The scatter-add backward passes (fp32 atomics) raise the alert the reference's CUDA backward raises
-    (csrc/knn/knn.cu:538 alertNotDeterministic) under torch.use_deterministic_algorithms(True), warn with
-    warn_only=True, and the forward passes (deterministic) are unaffected."""
-    from pytorch3d_pointops_amd.functions import knn_gather, knn_points
+def test_deterministic_backward_passes(dev, oracle):
+    """torch.use_deterministic_algorithms(True): the scatter sides of the backward passes run through the inverted
+    neighbour table (csrc/backward_det.hip) -- two runs are bit-identical, grad_p2 is BIT-EQUAL to the reference's CPU
+    backward (the knn_backward.npz goldens, and the oracle on a table with hubs, -1 padding and ragged lengths), and
+    chamfer_distance (composed path) and knn_gather train under the flag instead of raising."""
+    from pytorch3d_pointops_amd import _C
+    from pytorch3d_pointops_amd.functions import ball_query, knn_gather, knn_points
     from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance
 
-    a = G(cases.cloud(2301, (2, 300, 3)), dev).requires_grad_(True)
-    b = G(cases.cloud(2302, (2, 400, 3)), dev).requires_grad_(True)
+    g = load_golden("knn_backward")
+    for name, c in sorted(cases.knn_backward_cases().items()):
+        p1t, p2t, l1t, l2t = G(c["p1"], dev), G(c["p2"], dev), G(c["l1"], dev), G(c["l2"], dev)
+        idx, dists = _C.knn_points_idx(p1t, p2t, l1t, l2t, c["norm"], c["K"], -1)
+        grad = G(cases.grad_for(name, tuple(dists.shape)), dev)
+        g1, g2 = _C.knn_points_backward(p1t, p2t, l1t, l2t, idx, c["norm"], grad, deterministic=True)
+        assert np.array_equal(bits(g1.cpu().numpy()), bits(g[name + "/grad_p1"])), name
+        assert np.array_equal(bits(g2.cpu().numpy()), bits(g[name + "/grad_p2"])), name  # (1e-5 with atomics)
+    # hubs (every query's nearest neighbours are the same few points), ragged lengths, ball-query padding
+    p1 = cases.cloud(3401, (3, 3000, 3))
+    p2 = cases.cloud(3402, (3, 500, 3))
+    p2[1, 5:] += np.float32(10.0)  # cloud 1: five hubs take every entry
+    l1, l2 = np.array([3000, 2000, 7]), np.array([500, 500, 3])
+    for norm in (2, 1):
+        oi, od = oracle.knn_points_idx(p1, p2, l1, l2, norm, 8)
+        gd = cases.cloud(3403, (3, 3000, 8))
+        e1, e2 = oracle.knn_points_backward(p1, p2, l1, l2, oi, norm, gd)
+        a = _C.knn_points_backward(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), G(oi, dev), norm, G(gd, dev),
+                                   deterministic=True)
+        assert np.array_equal(bits(a[0].cpu().numpy()), bits(e1)) and np.array_equal(bits(a[1].cpu().numpy()), bits(e2))
+    bi, bd = oracle.ball_query(p1, p2, l1, l2, 6, 0.3)
+    gd = cases.cloud(3404, (3, 3000, 6))
+    e1, e2 = oracle.knn_points_backward(p1, p2, l1, l2, bi, 2, gd)
+    a = _C.knn_points_backward(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), G(bi, dev), 2, G(gd, dev),
+                               deterministic=True)
+    assert np.array_equal(bits(a[0].cpu().numpy()), bits(e1)) and np.array_equal(bits(a[1].cpu().numpy()), bits(e2))
+
+    x = G(cases.cloud(2301, (2, 3000, 3)), dev)
+    y = G(cases.cloud(2302, (2, 4000, 3)), dev)
+    xn, yn = G(cases.cloud(2303, (2, 3000, 3)), dev), G(cases.cloud(2304, (2, 4000, 3)), dev)
+
+    def train_step():
+        t = [v.clone().requires_grad_(True) for v in (x, y, xn, yn)]
+        r = knn_points(t[0], t[1], K=4)
+        b = ball_query(t[0], t[1], K=5, radius=0.1, return_nn=False)
+        loss, lf = chamfer_distance(t[0], t[1], x_features={"n": t[2]}, y_features={"n": t[3]}, feature_names=["n"])
+        total = r.dists.sum() + b.dists.sum() + knn_gather(t[3], r.idx).square().sum() + loss + lf["n"]
+        total.backward()
+        return [v.grad.clone() for v in t]
+
+    ref = train_step()  # default (atomics / LDS tiles)
     try:
         torch.use_deterministic_algorithms(True)
-        r = knn_points(a, b, K=4)  # forward: fine
-        with pytest.raises(RuntimeError, match="does not have a deterministic implementation"):
-            r.dists.sum().backward()
-        with pytest.raises(RuntimeError, match="does not have a deterministic implementation"):
-            knn_gather(b, r.idx).sum().backward()
-        loss, _ = chamfer_distance(a, b)
-        with pytest.raises(RuntimeError, match="does not have a deterministic implementation"):
-            loss.backward()
-        torch.use_deterministic_algorithms(True, warn_only=True)
-        with pytest.warns(UserWarning, match="does not have a deterministic implementation"):
-            knn_points(a, b, K=4).dists.sum().backward()
+        d1, d2 = train_step(), train_step()
     finally:
         torch.use_deterministic_algorithms(False)
-    assert a.grad is not None
+    for u, v, w in zip(d1, d2, ref):
+        assert torch.equal(u, v)  # reproducible, bit for bit
+        assert close(u.cpu().numpy(), w.cpu().numpy(), tol=2e-5)  # and the same gradients as the default passes
+    # the fused chamfer kernels still announce their atomics when called directly under the flag
+    from pytorch3d_pointops_amd.functions._common import alert_not_deterministic
+
+    try:
+        torch.use_deterministic_algorithms(True)
+        with pytest.raises(RuntimeError, match="does not have a deterministic implementation"):
+            alert_not_deterministic("chamfer_distance backward")
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        with pytest.warns(UserWarning, match="does not have a deterministic implementation"):
+            alert_not_deterministic("chamfer_distance backward")
+    finally:
+        torch.use_deterministic_algorithms(False)
 
 
 def test_chamfer_device_and_layout_checks(dev):
@@ -1091,12 +1136,19 @@ def test_chamfer_device_and_layout_checks(dev):
     assert torch.equal(l_s, l_c)
 
 
+@pytest.mark.parametrize("long_box", ["auto", "0", "1"])
 @pytest.mark.parametrize("K,norm", [(33, 2), (40, 2), (64, 2), (64, 1)])
-def test_knn_grid_long_lists(dev, oracle, K, norm):
+def test_knn_grid_long_lists(dev, oracle, monkeypatch, K, norm, long_box):
     """K in (32, 64] through the grid family (64-slot lists in the lane search, no quad pass, the long-list
     brute-force kernel as the exact fallback for what stays uncertified): ragged clouds, a cluster, a cloud
-    shorter than K and one without a usable grid, against the oracle and against the brute-force family."""
+    shorter than K and one without a usable grid, against the oracle and against the brute-force family.
+    `grid_long_box` = 1 / 0 forces the two routes of the uncertified queries (box search -- what big batches take
+    by themselves -- / wave search); with the box route the diagnostics must show queries deferred to it."""
+    from pytorch3d_pointops_amd import _C
     from pytorch3d_pointops_amd.functions import knn_points
+
+    if long_box != "auto":
+        monkeypatch.setenv("POINTOPS_DEBUG", "grid_long_box=" + long_box)
 
     p1 = cases.cloud(2501, (4, 2500, 3))
     p2 = cases.cloud(2502, (4, 12000, 3))
@@ -1110,6 +1162,17 @@ def test_knn_grid_long_lists(dev, oracle, K, norm):
     assert np.array_equal(bits(r.dists.cpu().numpy()), bits(od))
     r0 = knn_points(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm=norm, K=K, version=0)
     assert torch.equal(r0.idx, r.idx) and torch.equal(r0.dists, r.dists)
+    if long_box == "1":
+        # column 8 = queries handed to the box search, column 5 = the wave search's list (the lane pass's uncertified
+        # queries without the box route, what the box search could not certify with it)
+        args = (G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm, K)
+        box_on = _C.knn_grid_stats(*args)[2].cpu().numpy()
+        monkeypatch.setenv("POINTOPS_DEBUG", "grid_long_box=0")
+        box_off = _C.knn_grid_stats(*args)[2].cpu().numpy()
+        assert int(box_off[:2, 5].sum()) > 0, box_off  # there ARE uncertified queries on these clouds
+        # (the wave list of the run without the route also holds the few queries its box search gave up on)
+        assert int(box_on[:2, 8].sum()) > int(box_off[:2, 8].sum()), (box_on, box_off)
+        assert int(box_on[:2, 8].sum()) >= int(box_off[:2, 5].sum()) - int(box_off[:2, 8].sum()), (box_on, box_off)
 
 
 @pytest.mark.parametrize("K,norm", [(1, 2), (8, 2), (16, 1), (40, 2)])
@@ -1207,3 +1270,211 @@ def test_chamfer_backward_accumulate_equals_sum_of_directions(dev):
     assert bool((gx[1, 333:] == 0).all()) and bool((gy[1, 10:] == 0).all())
     with pytest.raises(RuntimeError, match="into"):
         _C.chamfer_backward(y, x, idx_yx, yl, xl, None, g, 2, yf, xf, True, True, into=(gx, gy, gxf, gyf))
+
+
+def test_integer_arguments_must_be_int64(dev):
+    """The kernels read lengths / idx / K / start_idxs as int64 through raw pointers; an int32 tensor would be read
+    past its buffer and give wrong neighbours with rc 0.  Every operator raises instead, like the reference's
+    accessor<int64_t, 1> (knn_cpu.cpp:84-88, ball_query_cpu.cpp:28-29, sample_farthest_points_cpu.cpp:33-36)."""
+    from pytorch3d_pointops_amd import _C
+    from pytorch3d_pointops_amd.functions import ball_query
+
+    p = G(cases.cloud(3301, (2, 64, 3)), dev)
+    L = torch.full((2,), 64, dtype=torch.int64, device=dev)
+    L32 = L.to(torch.int32)
+    idx, d = _C.knn_points_idx(p, p, L, L, 2, 4, -1)
+    g = torch.ones_like(d)
+    with pytest.raises(RuntimeError, match="int64"):
+        _C.knn_points_idx(p, p, L32, L, 2, 4, -1)
+    with pytest.raises(RuntimeError, match="int64"):
+        _C.ball_query(p, p, L32, L, 4, 0.2)
+    with pytest.raises(RuntimeError, match="int64"):
+        _C.ball_query(p, p, L, L32, 4, 0.2)
+    with pytest.raises(RuntimeError, match="int64"):
+        ball_query(p, p, L32, L32, K=4, radius=0.2)
+    with pytest.raises(RuntimeError, match="int64"):
+        _C.knn_points_backward(p, p, L32, L, idx, 2, g)
+    with pytest.raises(RuntimeError, match="int64"):
+        _C.knn_points_backward(p, p, L, L, idx.to(torch.int32), 2, g)
+    K = torch.full((2,), 8, dtype=torch.int64, device=dev)
+    S = torch.zeros((2,), dtype=torch.int64, device=dev)
+    for bad in ((L32, K, S), (L, K.to(torch.int32), S), (L, K, S.to(torch.int32))):
+        with pytest.raises(RuntimeError, match="int64"):
+            _C.sample_farthest_points(p, *bad)
+    with pytest.raises(RuntimeError, match="inconsistent shapes"):
+        _C.ball_query(p, p[:1], L, L, 4, 0.2)
+    assert _C.sample_farthest_points(p, L, K, S).shape == (2, 8)
+
+
+def test_cfg4_smallest_pair_loss_and_gradients_vs_oracle(dev, oracle):
+    """BASELINE.json configs[3] at full size (B=8 ragged 20k..200k, normals, fwd+bwd): the per-cloud loss
+    (batch_reduction=None) and all four gradients of the batch's SMALLEST cloud pair against a chamfer built from the
+    CPU oracle alone (both K=1 searches + knn_points_backward; the cosine term and its gradient in numpy), 1e-5."""
+    from pytorch3d_pointops_amd import synth
+    from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance
+
+    Bq = 8
+    l1 = synth.randint(41, 20000, 200000, (Bq,))
+    l2 = synth.randint(42, 20000, 200000, (Bq,))
+    P1, P2 = int(l1.max()), int(l2.max())
+    base = dict(x=synth.uniform_f32(43, (Bq, P1, 3)), y=synth.uniform_f32(44, (Bq, P2, 3)),
+                xn=synth.unit_normals(45, (Bq, P1, 3)), yn=synth.unit_normals(46, (Bq, P2, 3)))
+    wv = np.linspace(0.5, 1.5, Bq).astype(np.float32)
+    t = {k: G(v, dev).requires_grad_(True) for k, v in base.items()}
+    loss, lf = chamfer_distance(t["x"], t["y"], x_lengths=G(l1, dev), y_lengths=G(l2, dev),
+                                x_features={"normals": t["xn"]}, y_features={"normals": t["yn"]},
+                                feature_names=["normals"], weights=G(wv, dev), batch_reduction=None)
+    (loss.sum() + lf["normals"].sum()).backward()
+
+    n = int(np.argmin(l1.astype(np.int64) * l2.astype(np.int64)))
+    a, b = int(l1[n]), int(l2[n])
+    x, y = base["x"][n:n + 1, :a], base["y"][n:n + 1, :b]
+    xn, yn = base["xn"][n, :a].astype(np.float64), base["yn"][n, :b].astype(np.float64)
+    la, lb = np.array([a]), np.array([b])
+    i1, d1 = oracle.knn_points_idx(x, y, la, lb, 2, 1)
+    i2, d2 = oracle.knn_points_idx(y, x, lb, la, 2, 1)
+    w = float(wv[n])
+    exp_loss = w * (d1.astype(np.float64).sum() / a + d2.astype(np.float64).sum() / b)
+    assert abs(float(loss[n]) - exp_loss) <= 1e-5 * max(1.0, abs(exp_loss))
+
+    def cos_term(u, v):  # 1 - |cos(u, v)| per row and its gradients (torch: dot / max(|u| |v|, eps), eps = 1e-6)
+        nu, nv = np.linalg.norm(u, axis=1), np.linalg.norm(v, axis=1)
+        den = np.maximum(nu * nv, 1e-6)
+        c = (u * v).sum(1) / den
+        sgn = np.sign(c)
+        gu = -(sgn / den)[:, None] * (v - (c * nv / nu)[:, None] * u)
+        gv = -(sgn / den)[:, None] * (u - (c * nu / nv)[:, None] * v)
+        return 1.0 - np.abs(c), gu, gv
+
+    j1, j2 = i1[0, :, 0], i2[0, :, 0]
+    tx, gxa, gyb = cos_term(xn, yn[j1])
+    ty, gyc, gxd = cos_term(yn, xn[j2])
+    exp_feat = w * (tx.sum() / a + ty.sum() / b)
+    assert abs(float(lf["normals"][n]) - exp_feat) <= 1e-5 * max(1.0, abs(exp_feat))
+    # point gradients: knn backward of both directions with grad_dists = w / length
+    g1 = np.full(d1.shape, w / a, np.float32)
+    g2 = np.full(d2.shape, w / b, np.float32)
+    ax, ay = oracle.knn_points_backward(x, y, la, lb, i1, 2, g1)
+    by, bx = oracle.knn_points_backward(y, x, lb, la, i2, 2, g2)
+    assert close(t["x"].grad[n, :a].cpu().numpy(), (ax + bx)[0], tol=1e-5)
+    assert close(t["y"].grad[n, :b].cpu().numpy(), (ay + by)[0], tol=1e-5)
+    assert not bool(t["x"].grad[n, a:].any()) and not bool(t["y"].grad[n, b:].any())
+    # normal gradients: dense rows of the own direction + the scatter of the other one
+    gxn = (w / a) * gxa
+    np.add.at(gxn, j2, (w / b) * gxd)
+    gyn = (w / b) * gyc
+    np.add.at(gyn, j1, (w / a) * gyb)
+    assert close(t["xn"].grad[n, :a].cpu().numpy(), gxn.astype(np.float32), tol=1e-5)
+    assert close(t["yn"].grad[n, :b].cpu().numpy(), gyn.astype(np.float32), tol=1e-5)
+
+
+def test_reference_example_call_patterns_2(dev):
+    """The call patterns of five more of the reference's self-checking example scripts at their own sizes
+    (ball_query_on_pointclouds.py:50-125, fps_on_pointclouds.py:66-215, chamfer_loss.py:13-89,
+    packed_to_padded_on_pointclouds.py:67-124, utils_on_pointclouds.py:69-237) against the outputs the REFERENCE
+    produced for the same inputs (tests/golden/examples2.npz + examples2_meta.json, made by make_golden.py
+    gen_examples2 in the build container): indices, distances, gathers and copies bit-exact, losses / covariances /
+    weighted means within 1e-5."""
+    import hashlib
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from pytorch3d_pointops_amd.functions import (ball_query, knn_points, masked_gather, packed_to_padded,
+                                                  padded_to_packed, sample_farthest_points)
+    from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance
+    from pytorch3d_pointops_amd.functions.sample_farthest_points import sample_farthest_points_naive
+    from pytorch3d_pointops_amd.functions.utils import get_point_covariances, wmean
+    from pytorch3d_pointops_amd.structures import Pointclouds
+
+    g = load_golden("examples2")
+    meta = json.load(open(os.path.join(GOLDEN, "examples2_meta.json")))
+    inp = cases.example2_inputs()
+
+    def same(tag, t):
+        a = t.detach().cpu().numpy()
+        if a.dtype == np.int64:
+            a = a.astype(np.int32)
+        if tag in meta:
+            assert list(a.shape) == meta[tag]["shape"] and str(a.dtype) == meta[tag]["dtype"], tag
+            flat = a.reshape(-1, a.shape[-1]) if a.ndim > 1 else a
+            assert np.array_equal(np.ascontiguousarray(flat[::37]).view(np.int32), g[tag + "/rows"].view(np.int32)), tag
+            assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == meta[tag]["sha256"], tag
+        else:
+            assert a.shape == g[tag].shape and np.array_equal(a.view(np.int32), g[tag].view(np.int32)), tag
+
+    # ---- ball query
+    b = inp["ball"]
+    pc = Pointclouds(points=[G(a, dev) for a in b["points"]])
+    pad, lens = pc.points_padded(), pc.num_points_per_cloud()
+    r = ball_query(p1=pad, p2=pad, lengths1=lens, lengths2=lens, K=50, radius=0.3, return_nn=True)
+    same("ball/dists", r.dists), same("ball/idx", r.idx), same("ball/knn", r.knn)
+    valid = r.idx[0] != -1
+    assert bool((torch.sqrt(r.dists[0][valid]) <= 0.3).all())  # the script's own check (:113-117)
+    lat = G(b["lattice"], dev)[None]
+    r = ball_query(p1=lat, p2=lat, K=30, radius=0.25, return_nn=False)
+    k = knn_points(p1=lat, p2=lat, K=10, return_nn=False)
+    same("lattice/ball_dists", r.dists), same("lattice/ball_idx", r.idx)
+    same("lattice/knn_dists", k.dists), same("lattice/knn_idx", k.idx)
+    # ---- FPS (random starts: the same torch.manual_seed as the generator, the same RNG consumption as the reference)
+    f = inp["fps"]
+    torch.manual_seed(123)
+    sp, si = sample_farthest_points(G(f["single"], dev)[None], K=50, random_start_point=True)
+    same("fps/single_idx", si), same("fps/single_points", sp)
+    pc = Pointclouds(points=[G(a, dev) for a in f["points"]])
+    torch.manual_seed(42)
+    sp, si = sample_farthest_points(pc.points_padded(), lengths=pc.num_points_per_cloud(), K=[100, 80, 150],
+                                    random_start_point=True)
+    same("fps/batch_idx", si), same("fps/batch_points", sp)
+    so, io = sample_farthest_points(G(f["compare"], dev), K=200, random_start_point=False)
+    sn, in_ = sample_farthest_points_naive(G(f["compare"], dev), K=200, random_start_point=False)
+    assert torch.equal(io, in_) and torch.equal(so, sn)  # the script's own check (:141-149)
+    same("fps/compare_idx", io)
+    torch.manual_seed(7)
+    sp, si = sample_farthest_points(G(f["points"][0], dev)[None], K=100, random_start_point=True)
+    same("fps/colors_idx", si), same("fps/colors", masked_gather(G(f["colors0"], dev)[None], si))
+    sn, in_ = sample_farthest_points_naive(G(f["circles"], dev)[None], K=50, random_start_point=False)
+    same("fps/circles_idx", in_)
+    _, ih = sample_farthest_points(G(f["circles"], dev)[None], K=50)  # (the HIP kernel on the 2-D cloud)
+    assert torch.equal(ih, in_)
+    # ---- chamfer
+    c = {kk: G(v, dev) for kk, v in inp["chamfer"].items()}
+    l, lf = chamfer_distance(c["p1"], c["p2"], x_features={"normals": c["n1"], "colors": c["c1"]},
+                             y_features={"normals": c["n2"], "colors": c["c2"]}, feature_names=["normals", "colors"])
+    assert close(np.array([float(l), float(lf["normals"]), float(lf["colors"])]), g["chamfer/tensor"], tol=1e-5)
+    pc1 = Pointclouds(points=list(c["p1"]), features={"normals": list(c["n1"]), "colors": list(c["c1"])})
+    pc2 = Pointclouds(points=list(c["p2"]), features={"normals": list(c["n2"]), "colors": list(c["c2"])})
+    l, lf = chamfer_distance(pc1, pc2, feature_names=["normals", "colors"])
+    assert close(np.array([float(l), float(lf["normals"]), float(lf["colors"])]), g["chamfer/pointclouds"], tol=1e-5)
+    l, lf = chamfer_distance(pc1, pc2, feature_names=["normals"], single_directional=True)
+    assert close(np.array([float(l), float(lf["normals"])]), g["chamfer/single"], tol=1e-5)
+    # ---- packed <-> padded
+    kq = inp["packed"]
+    pc = Pointclouds(points=[G(a, dev) for a in kq["points"]],
+                     features={"intensities": [G(a, dev) for a in kq["intensities"]]})
+    lens = pc.num_points_per_cloud()
+    first = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), lens.cumsum(0)[:-1]])
+    pp, ip = pc.points_packed(), pc.get_features_packed("intensities")
+    pad, ipad = packed_to_padded(pp, first, int(lens.max())), packed_to_padded(ip, first, int(lens.max()))
+    same("packed/points_packed", pp), same("packed/points_padded", pad), same("packed/intensities_padded", ipad)
+    same("packed/points_repacked", padded_to_packed(pad, first, int(lens.sum())))
+    same("packed/intensities_repacked", padded_to_packed(ipad, first, int(lens.sum())))
+    pc = Pointclouds(points=[G(a, dev) for a in kq["var_points"]],
+                     features={"features": [G(a, dev) for a in kq["var_features"]]})
+    lens = pc.num_points_per_cloud()
+    first = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), lens.cumsum(0)[:-1]])
+    fpad = packed_to_padded(pc.get_features_packed("features"), first, int(lens.max()))
+    same("packed/var_features_padded", fpad)
+    same("packed/var_features_repacked", padded_to_packed(fpad, first, int(lens.sum())))
+    # ---- utils
+    u = inp["utils"]
+    pc = Pointclouds(points=[G(a, dev) for a in u["points"]])
+    cov, nn = get_point_covariances(pc.points_padded(), pc.num_points_per_cloud(), 16)
+    assert close(cov.cpu().numpy()[:, ::5], g["utils/cov"], tol=1e-5)
+    same("utils/cov_knn", nn)
+    wm = np.stack([wmean(G(p, dev), G(w, dev).squeeze(), dim=0, keepdim=False).cpu().numpy()
+                   for p, w in zip(u["points"], u["weights"])])
+    assert close(wm, g["utils/wmean"], tol=1e-5)
+    p0 = G(u["points"][0], dev)[None]
+    kn = knn_points(p0, p0, K=8, return_nn=False)
+    same("utils/knn_idx", kn.idx), same("utils/gathered_values", masked_gather(G(u["values"][0], dev)[None], kn.idx))

@@ -86,7 +86,7 @@ def _worker(rank, world, port, q):
                                             batch_reduction="mean", local_fn=local_fn)
         loss.backward()
         # raw gather with uneven counts
-        vec = all_gather_losses(torch.arange(s, e, dtype=torch.float32), [3, 2])
+        vec = all_gather_losses(torch.arange(s, e, dtype=torch.float32), [b - a for a, b in shard_bounds(B, world)])
         # cost-balanced placement of the ragged batch (cost = len1 * len2): rank r owns clouds plan[r]
         from pytorch3d_pointops_amd.sharded import plan_shards
 
@@ -109,9 +109,11 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_chamfer_matches_single_process_gloo():
-    world = 2
-    port = 29500 + (os.getpid() % 2000)
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_chamfer_matches_single_process_gloo(world):
+    """world_size 2 (3 + 2 clouds) and 4 (2 + 1 + 1 + 1 clouds, a cost-balanced assignment with ranks of 1 and 2
+    clouds): the same loss on every rank, gradients equal to the single-process run."""
+    port = 29500 + (os.getpid() % 2000) + 7 * world
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -136,20 +138,56 @@ def test_sharded_chamfer_matches_single_process_gloo():
     per = _oracle_chamfer_per_cloud(xt, yt, xl, yl, torch.from_numpy(w))
     full = per.sum() / float(w.sum())
     full.backward()
-    assert abs(res[0][0] - float(full)) <= 1e-6 and res[0][0] == res[1][0]  # identical on every rank
-    gx = np.concatenate([res[0][1], res[1][1]])
-    gy = np.concatenate([res[0][2], res[1][2]])
+    assert abs(res[0][0] - float(full)) <= 1e-6 and all(res[r][0] == res[0][0] for r in range(world))  # identical on every rank
+    gx = np.concatenate([res[r][1] for r in range(world)])
+    gy = np.concatenate([res[r][2] for r in range(world)])
     assert np.allclose(gx, xt.grad.numpy(), atol=1e-7) and np.allclose(gy, yt.grad.numpy(), atol=1e-7)
-    assert np.array_equal(res[0][3], np.arange(5, dtype=np.float32))
-    assert np.array_equal(res[1][3], np.arange(5, dtype=np.float32))
+    for r in range(world):
+        assert np.array_equal(res[r][3], np.arange(5, dtype=np.float32))
     # balanced placement: a non-contiguous plan, per-cloud vector back in GLOBAL cloud order, same loss / grads
     plan = res[0][4]
-    assert plan == res[1][4] and sorted(plan[0] + plan[1]) == list(range(B))
-    assert plan != [[0, 1, 2], [3, 4]]
+    assert all(res[r][4] == plan for r in range(world)) and sorted(sum(plan, [])) == list(range(B))
+    from pytorch3d_pointops_amd.sharded import shard_bounds
+
+    assert plan != [list(range(a, b)) for a, b in shard_bounds(B, world)]
     cost = (xl * yl).astype(np.float64)
     loads = [cost[ids].sum() for ids in plan]
-    assert abs(loads[0] - loads[1]) <= cost.max()
+    assert max(loads) - min(loads) <= cost.max()
     for r in range(world):
         assert np.allclose(res[r][5], per.detach().numpy(), atol=1e-7)
         assert abs(res[r][6] - float(full)) <= 1e-6
         assert np.allclose(res[r][7], xt.grad.numpy()[plan[r]], atol=1e-7)
+
+
+def test_bench_launcher_fails_fast_when_a_rank_dies(tmp_path):
+    """`bench.py --gpus N` run as its own launcher: a rank that dies must end the run with exit code 1 within seconds,
+    even while rank 0 sits in a barrier it can never leave (stub rank body: rank 1 exits 3 at once, the others sleep)."""
+    import subprocess
+    import sys
+    import time
+    import types
+
+    import bench
+
+    stub = tmp_path / "rank.py"
+    stub.write_text("import os, sys, time\n"
+                    "if os.environ['RANK'] == '1':\n    sys.exit(3)\n"
+                    "time.sleep(120)\nprint('{}')\n")
+    args = types.SimpleNamespace(gpus=3)
+    t0 = time.monotonic()
+    rc = bench.launch_ranks(args, rank_cmd=[sys.executable, str(stub)], wall_limit_s=60)
+    assert rc == 1 and time.monotonic() - t0 < 20
+    # all ranks healthy: rank 0's line is relayed, exit code 0
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os\nif os.environ['RANK'] == '0':\n    print('{\"ok\": 1}')\n")
+    r = subprocess.run([sys.executable, "-c",
+                        "import sys, types; sys.path.insert(0, %r); import bench; "
+                        "sys.exit(bench.launch_ranks(types.SimpleNamespace(gpus=2), rank_cmd=[sys.executable, %r]))"
+                        % (str(bench.ROOT), str(ok))], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and '{"ok": 1}' in r.stdout
+    # the wall-clock limit also ends a run in which nobody fails
+    hang = tmp_path / "hang.py"
+    hang.write_text("import time\ntime.sleep(120)\n")
+    t0 = time.monotonic()
+    assert bench.launch_ranks(types.SimpleNamespace(gpus=2), rank_cmd=[sys.executable, str(hang)], wall_limit_s=1.0) == 1
+    assert time.monotonic() - t0 < 20
