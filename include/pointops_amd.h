@@ -64,6 +64,24 @@ int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* len
                             void* stream);
 
 /*
+ * The same operator REUSING the cell grid a previous call left in `workspace` (the grid-pruned family only:
+ * pointops_knn_uses_grid(...) != 0 for the shape; other families ignore `reuse`).  The reference has no counterpart --
+ * its operator (csrc/knn/knn.h:59-66) is stateless -- so this is an extension for callers that query the same target
+ * cloud repeatedly (chamfer against a fixed ground truth, knn_points followed by more queries of the same cloud):
+ *   reuse = 0  build everything (= pointops_knn_points_idx);
+ *   reuse = 1  p2, lengths2, N, P1, P2, D, K and version are those of the previous call into this workspace and the
+ *              bytes of p2 / lengths2 are unchanged: the bounding boxes, cell tables, the sort of p2 and its refined
+ *              cells are reused, only the queries are sorted;
+ *   reuse = 2  p1 and lengths1 are unchanged too: no build pass runs at all.
+ * The caller vouches for these conditions; results equal reuse = 0 bit for bit when they hold.
+ */
+int pointops_knn_uses_grid(int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K, int version);
+int pointops_knn_points_idx_reuse(const float* p1, const float* p2, const int64_t* lengths1,
+                                  const int64_t* lengths2, int64_t N, int64_t P1, int64_t P2, int64_t D,
+                                  int norm, int64_t K, int version, int64_t* idxs, float* dists,
+                                  void* workspace, size_t workspace_bytes, int reuse, void* stream);
+
+/*
  * Diagnostics for the grid-pruned KNN family (version 3): after a pointops_knn_points_idx
  * call that used `workspace`, copies the per-cloud number of queries that the pruning
  * bound could not certify (and that were answered by the whole-cloud scan instead) into

@@ -32,6 +32,9 @@ _SIGNATURES = {
     "pointops_knn_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64, _int]),
     "pointops_knn_points_idx": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _i64, _int,
                                        _vp, _vp, _vp, _sz, _vp]),
+    "pointops_knn_uses_grid": (_int, [_i64, _i64, _i64, _i64, _i64, _int]),
+    "pointops_knn_points_idx_reuse": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _i64, _int,
+                                             _vp, _vp, _vp, _sz, _int, _vp]),
     "pointops_knn_check_version": (_int, [_int, _i64, _i64]),
     "pointops_knn_grid_fallback_counts": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "pointops_knn_grid_stats": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
@@ -138,6 +141,63 @@ def _stream():
 
 
 # ---------------------------------------------------------------------------
+# Grid reuse (opt-in): the cell grid of the exact search is an index over p2 -- bounding boxes, cell tables, the
+# cell-sorted copy of the cloud, refined cells: 123 us of a 705 us call at B=32, N=M=65536, K=16 -- that a second
+# query of the SAME target cloud does not have to rebuild (chamfer against a fixed ground truth, knn_points followed
+# by further queries).  With the switch on, knn_points_idx keeps the workspaces of its last few grid calls and hands
+# them back to the C ABI (pointops_knn_points_idx_reuse) when the target tensors are provably the ones it was built
+# from: the same tensor OBJECTS (weak references), the same data pointers and the same autograd version counters --
+# every in-place op of PyTorch bumps that counter.  It is OFF by default because one kind of write is invisible to
+# it: `p2.data.copy_(...)` / a raw-pointer write from another library changes the bytes without the counter, and a
+# stale grid then answers for the OLD points (the reference's stateless operator has no such failure mode).
+#   pytorch3d_pointops_amd.set_grid_cache(True [, max_entries])      or      POINTOPS_GRID_CACHE=1
+# ---------------------------------------------------------------------------
+import collections
+import weakref
+
+_GRID_CACHE = collections.OrderedDict()
+_GRID_CACHE_ON = os.environ.get("POINTOPS_GRID_CACHE", "0") not in ("", "0")
+_GRID_CACHE_MAX = 2
+grid_cache_stats = {"miss": 0, "points": 0, "both": 0}
+
+
+def set_grid_cache(enabled: bool, max_entries: int = 2) -> None:
+    """Switch the grid reuse of knn_points_idx on or off (off: the default; cached workspaces are dropped)."""
+    global _GRID_CACHE_ON, _GRID_CACHE_MAX
+    _GRID_CACHE_ON = bool(enabled)
+    _GRID_CACHE_MAX = max(1, int(max_entries))
+    if not enabled:
+        _GRID_CACHE.clear()
+
+
+def _sig(t):
+    return (id(t), t._version, t.data_ptr(), tuple(t.shape))
+
+
+def _grid_workspace(p1, p2, lengths1, lengths2, shape, ws_bytes, dev):
+    """(workspace, reuse level) for a grid call: level 2 when both point sets are the cached call's, 1 when the
+    target side is, 0 (a fresh workspace, remembered) otherwise."""
+    key = (_sig(p2), _sig(lengths2), shape, _stream(), str(dev))
+    hit = _GRID_CACHE.get(key)
+    if hit is not None and hit["p2"]() is p2 and hit["l2"]() is lengths2 and hit["ws"].numel() == ws_bytes:
+        _GRID_CACHE.move_to_end(key)
+        q = (_sig(p1), _sig(lengths1))
+        level = 2 if (hit["q"] == q and hit["p1"]() is p1 and hit["l1"]() is lengths1) else 1
+        hit.update(q=q, p1=weakref.ref(p1), l1=weakref.ref(lengths1))
+        grid_cache_stats["both" if level == 2 else "points"] += 1
+        return hit["ws"], level
+    grid_cache_stats["miss"] += 1
+    for k in [k for k, v in _GRID_CACHE.items() if v["p2"]() is None]:
+        del _GRID_CACHE[k]  # entries whose target tensor has died
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    _GRID_CACHE[key] = dict(ws=ws, p2=weakref.ref(p2), l2=weakref.ref(lengths2), q=(_sig(p1), _sig(lengths1)),
+                            p1=weakref.ref(p1), l1=weakref.ref(lengths1))
+    while len(_GRID_CACHE) > _GRID_CACHE_MAX:
+        _GRID_CACHE.popitem(last=False)
+    return ws, 0
+
+
+# ---------------------------------------------------------------------------
 # reference: csrc/knn/knn.h:59-80 -- returns (idx, dists), NOT (dists, idx)
 # ---------------------------------------------------------------------------
 def knn_points_idx(p1, p2, lengths1, lengths2, norm: int, K: int, version: int = -1):
@@ -158,13 +218,17 @@ def knn_points_idx(p1, p2, lengths1, lengths2, norm: int, K: int, version: int =
         idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
         dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
         ws_bytes = _lib.pointops_knn_workspace_bytes(N, P1, P2, D, K, version)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+        reuse = 0
+        if _GRID_CACHE_ON and ws_bytes and _lib.pointops_knn_uses_grid(N, P1, P2, D, int(K), int(version)):
+            ws, reuse = _grid_workspace(p1, p2, lengths1, lengths2, (N, P1, P2, D, int(K), int(version)), ws_bytes, dev)
+        else:
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
         _check(
-            _lib.pointops_knn_points_idx(p1.data_ptr(), p2.data_ptr(), lengths1.data_ptr(),
-                                         lengths2.data_ptr(), N, P1, P2, D, int(norm), int(K),
-                                         int(version), idxs.data_ptr(), dists.data_ptr(),
-                                         ws.data_ptr() if ws is not None else None, ws_bytes,
-                                         _stream()),
+            _lib.pointops_knn_points_idx_reuse(p1.data_ptr(), p2.data_ptr(), lengths1.data_ptr(),
+                                               lengths2.data_ptr(), N, P1, P2, D, int(norm), int(K),
+                                               int(version), idxs.data_ptr(), dists.data_ptr(),
+                                               ws.data_ptr() if ws is not None else None, ws_bytes, reuse,
+                                               _stream()),
             "knn_points_idx",
         )
     return idxs, dists

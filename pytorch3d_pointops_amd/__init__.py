@@ -12,3 +12,11 @@ __version__ = "0.1.0"
 # `pytorch3d_pointops_amd.build` must stay importable before the library exists, so nothing is imported here:
 # `functions` (and `structures`, which uses it) load `_C` -- the ctypes boundary, raising when the .so is
 # missing -- and `ops`, which registers torch.ops.pointops_amd.*.
+
+
+def set_grid_cache(enabled: bool, max_entries: int = 2) -> None:
+    """Opt in to (or out of) the reuse of the exact search's cell grid between calls that query the same, unmodified
+    target tensor -- see `_C.set_grid_cache` for what "unmodified" can and cannot see."""
+    from . import _C
+
+    _C.set_grid_cache(enabled, max_entries)

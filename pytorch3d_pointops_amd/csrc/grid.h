@@ -126,6 +126,9 @@ __device__ __forceinline__ int sub_of(float x, float lo, float scale, int s) {
 size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, float c_target, bool ball = false);
 // bbox, cell size, edge tables, counting sorts of points and queries, chunk prefix; stream-ordered
 int grid_build(const KnnArgs& a, const GridWs& ws, const GridBuild& b);
+// the query side only, against a point side built by an earlier call into the same workspace (level 1: new queries,
+// level 2: the same queries); stream-ordered
+int grid_build_queries(const KnnArgs& a, const GridWs& ws, bool same, int level);
 // build the sub-grids of the cells grid_build marked (grid_refine.hip); stream-ordered behind grid_build
 int grid_refine(const KnnArgs& a, const GridWs& ws);
 

@@ -367,7 +367,7 @@ __device__ __forceinline__ int wave_add(int* __restrict__ counter, int slot, boo
 template <int D, bool SCATTER, bool QUERIES>
 __global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float* __restrict__ p2, int P2,
                                                                  const float* __restrict__ p1, int P1, int K,
-                                                                 GridWs ws, int64_t* __restrict__ idxs,
+                                                                 GridWs ws, int zbase, int64_t* __restrict__ idxs,
                                                                  float* __restrict__ dists) {
   constexpr int kPartPerThread = SCATTER ? kScatterPerThread : kCountPerThread;
   constexpr int kPartTile = kPartBlock * kPartPerThread;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kPartBlock) void grid_partition_kernel(const float*
   __shared__ int s_wsum[kPartBlock / kWave];
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
-  const bool IS_QUERY = QUERIES && blockIdx.z == 1;   // (workgroup-uniform)
+  const bool IS_QUERY = QUERIES && blockIdx.z + zbase == 1;   // (workgroup-uniform; zbase = 1: a queries-only launch)
   const bool PAD_ROWS = QUERIES ? IS_QUERY : true;    // the pass over the query index space also pads rows
   const float* __restrict__ pts = IS_QUERY ? p1 : p2;
   const int P = IS_QUERY ? P1 : P2;
@@ -630,11 +630,11 @@ __device__ __forceinline__ int fine_slot(int f) { return f + (f >> 5); }
 // record its rank inside its cell (fine_count / rank arrays), so its slices of kCrowdedSlice records are placed by as
 // many workgroups as there are slices, without atomics: position = cell start (scan of the bin's cell counts, redone
 // per slice from L2) + rank.
-__global__ __launch_bounds__(kSortBlock) void grid_sort_kernel(GridWs ws, int P1, int P2, int refine) {
+__global__ __launch_bounds__(kSortBlock) void grid_sort_kernel(GridWs ws, int P1, int P2, int refine, int zbase) {
   __shared__ int s_cnt[kFineMax + kFineMax / 32];
   __shared__ int s_wsum[kSortBlock / kWave];
   __shared__ int s_list[kCrowdedMax];
-  const int n = blockIdx.y, set = blockIdx.z;
+  const int n = blockIdx.y, set = blockIdx.z + zbase;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const GridCloud g = ws.cloud[n];
   const int len = set ? g.len1 : g.len2;
@@ -880,15 +880,18 @@ size_t grid_carve(GridWs* ws, char* base, int64_t N, int64_t P1, int64_t P2, flo
   return off;
 }
 
+// sets: 0 = points only (self-query), 1 = queries only (the point side is already built: grid_build_queries), 2 = both
 template <int D>
-static void build_d(const KnnArgs& a, const GridWs& ws, bool same, int refine) {
-  const unsigned sets = same ? 1u : 2u;  // points only / points and queries
-  const int64_t pmax = same ? a.P2 : (a.P2 > a.P1 ? a.P2 : a.P1);
+static void build_d(const KnnArgs& a, const GridWs& ws, int sets_mode, int refine) {
+  const bool same = sets_mode == 0;
+  const unsigned sets = sets_mode == 2 ? 2u : 1u;
+  const int zbase = sets_mode == 1 ? 1 : 0;
+  const int64_t pmax = same ? a.P2 : sets_mode == 1 ? a.P1 : (a.P2 > a.P1 ? a.P2 : a.P1);
 #define PO_PART(SCT, QRY)                                                                                         \
   hipLaunchKernelGGL((grid_partition_kernel<D, SCT, QRY>),                                                        \
                      dim3((unsigned)ceil_div(pmax, kPartBlock * (SCT ? kScatterPerThread : kCountPerThread)),     \
                           (unsigned)a.N, sets),                                                                   \
-                     dim3(kPartBlock), 0, a.stream, a.p2, a.P2, a.p1, a.P1, a.K, ws, a.idxs, a.dists)
+                     dim3(kPartBlock), 0, a.stream, a.p2, a.P2, a.p1, a.P1, a.K, ws, zbase, a.idxs, a.dists)
   if (same) {
     PO_PART(false, false);
     PO_PART(true, false);
@@ -899,12 +902,82 @@ static void build_d(const KnnArgs& a, const GridWs& ws, bool same, int refine) {
 #undef PO_PART
   // sort workgroups per (cloud, set): enough of them to fill the chip when the batch is small
   // (a cloud of P entries has at most P / kCoarsePoints + cells / kFineMax + 2 bins)
-  const int64_t bins = (same ? a.P2 : (a.P2 > a.P1 ? a.P2 : a.P1)) / kCoarsePoints + ws.cell_cap / kFineMax + 2;
+  const int64_t bins = pmax / kCoarsePoints + ws.cell_cap / kFineMax + 2;
   int64_t wgs = 8192 / (a.N * (int64_t)sets);
   wgs = wgs < 16 ? 16 : (wgs > kCoarseMax ? kCoarseMax : wgs);
   wgs = wgs > bins ? bins : wgs;
   hipLaunchKernelGGL(grid_sort_kernel, dim3((unsigned)wgs, (unsigned)a.N, sets), dim3(kSortBlock), 0, a.stream, ws,
-                     (int)a.P1, (int)a.P2, refine);
+                     (int)a.P1, (int)a.P2, refine, zbase);
+}
+
+// ---------------------------------------------------------------------------
+// REUSE of a built grid (pointops_knn_points_idx_reuse): the point side of the workspace -- cloud geometry, edge
+// tables, cell_start, sorted records, refined cells -- is still valid; a new query set only needs its own sort, an
+// unchanged one nothing but fresh counters and the padded rows of the new output tensors.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kSetupBlock) void grid_requery_kernel(const int64_t* __restrict__ lengths1, int P1, int same,
+                                                                GridWs ws) {
+  const int n = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int len1 = (int)lengths1[n];
+    len1 = len1 < 0 ? 0 : (len1 > P1 ? P1 : len1);
+    ws.cloud[n].len1 = len1;
+    ws.cloud[n].same = same;
+    ws.fb_count[n] = 0;
+    ws.fb2_count[n] = 0;
+    ws.fb3_count[n] = 0;
+    ws.box_count[n] = 0;
+    ws.coarse_ticket[n * 2 + 1] = 0;
+    ws.crowded_count[n * 2 + 1] = 0;
+    ws.nbins[n * 2 + 1] = 0;
+  }
+  for (int t = tid; t < kCoarseMax + 1; t += kSetupBlock) {  // counters and cursors of the query set's partition passes
+    ws.coarse_count[coarse_row(n, 1) + t] = 0;
+    ws.coarse_cursor[coarse_row(n, 1) + t] = 0;
+  }
+}
+
+// what the count launch does besides counting, for calls that skip it: the chunk prefix, the rows that get no search
+// (padded queries) and the whole-cloud list of clouds without a usable grid
+__global__ __launch_bounds__(kPartBlock) void grid_pad_prefix_kernel(GridWs ws, int P1, int K, int64_t* __restrict__ idxs,
+                                                                  float* __restrict__ dists) {
+  const int n = blockIdx.y, tid = threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < kWave) grid_chunk_prefix(ws, (int)gridDim.y);
+  const GridCloud g = ws.cloud[n];
+  if (g.len1 >= P1 && g.use_grid) return;  // (the usual case: nothing to pad, nothing to list)
+  constexpr int kTile = kPartBlock * kCountPerThread;
+  for (int r = 0; r < kCountPerThread; ++r) {
+    const int i = blockIdx.x * kTile + r * kPartBlock + tid;
+    if (i < P1 && i >= g.len1) {
+      int64_t* __restrict__ zi = idxs + ((int64_t)n * P1 + i) * K;
+      float* __restrict__ zd = dists + ((int64_t)n * P1 + i) * K;
+      const int64_t pad = ws.ball ? -1 : 0;
+      for (int k = 0; k < K; ++k) {
+        zi[k] = pad;
+        zd[k] = 0.0f;
+      }
+    } else if (i < g.len1 && !g.use_grid && !ws.ball) {
+      const int pos = atomicAdd(ws.fb2_count + n, 1);
+      ws.fb2_list[(int64_t)n * P1 + pos] = i;
+    }
+  }
+}
+
+// level 1: a new query set against the built point side; level 2: the same query set again
+int grid_build_queries(const KnnArgs& a, const GridWs& ws, bool same, int level) {
+  hipLaunchKernelGGL(grid_requery_kernel, dim3((unsigned)a.N), dim3(kSetupBlock), 0, a.stream, a.l1, a.P1, same ? 1 : 0,
+                     ws);
+  if (same || level >= 2) {
+    hipLaunchKernelGGL(grid_pad_prefix_kernel, dim3((unsigned)ceil_div(a.P1, kPartBlock * kCountPerThread), (unsigned)a.N),
+                       dim3(kPartBlock), 0, a.stream, ws, a.P1, a.K, a.idxs, a.dists);
+  } else {
+    switch (a.D) {
+      case 1: build_d<1>(a, ws, 1, -1); break;
+      case 2: build_d<2>(a, ws, 1, -1); break;
+      default: build_d<3>(a, ws, 1, -1); break;
+    }
+  }
+  return check_launch("grid build (queries)");
 }
 
 int grid_build(const KnnArgs& a, const GridWs& ws, const GridBuild& b) {
@@ -915,9 +988,9 @@ int grid_build(const KnnArgs& a, const GridWs& ws, const GridBuild& b) {
                      a.P2, a.D, b.c_target, b.h_min, b.ball_radius, b.ball_K, b.ball_factor, b.same ? 1 : 0, bbox_slots,
                      ws);
   switch (a.D) {
-    case 1: build_d<1>(a, ws, b.same, b.refine); break;
-    case 2: build_d<2>(a, ws, b.same, b.refine); break;
-    default: build_d<3>(a, ws, b.same, b.refine); break;
+    case 1: build_d<1>(a, ws, b.same ? 0 : 2, b.refine); break;
+    case 2: build_d<2>(a, ws, b.same ? 0 : 2, b.refine); break;
+    default: build_d<3>(a, ws, b.same ? 0 : 2, b.refine); break;
   }
   return check_launch("grid build");
 }

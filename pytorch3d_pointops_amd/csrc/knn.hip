@@ -311,6 +311,20 @@ int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* len
                             const int64_t* lengths2, int64_t N, int64_t P1, int64_t P2, int64_t D,
                             int norm, int64_t K, int version, int64_t* idxs, float* dists,
                             void* workspace, size_t workspace_bytes, void* stream) {
+  return pointops_knn_points_idx_reuse(p1, p2, lengths1, lengths2, N, P1, P2, D, norm, K, version, idxs, dists,
+                                       workspace, workspace_bytes, 0, stream);
+}
+
+int pointops_knn_uses_grid(int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K, int version) {
+  if (N <= 0 || P1 <= 0 || D < 1 || K < 1) return 0;
+  return choose_version(version, N, P1, P2, D, K) == 3 ? 1 : 0;
+}
+
+int pointops_knn_points_idx_reuse(const float* p1, const float* p2, const int64_t* lengths1,
+                                  const int64_t* lengths2, int64_t N, int64_t P1, int64_t P2, int64_t D,
+                                  int norm, int64_t K, int version, int64_t* idxs, float* dists,
+                                  void* workspace, size_t workspace_bytes, int reuse, void* stream) {
+  POINTOPS_REQUIRE(reuse >= 0 && reuse <= 2, "knn_points_idx: reuse must be 0, 1 or 2");
   POINTOPS_REQUIRE(norm == 1 || norm == 2, "knn_points_idx: norm must be 1 or 2 (got %d)", norm);
   POINTOPS_REQUIRE(N >= 0 && P1 >= 0 && P2 >= 0 && D >= 1 && K >= 1,
                    "knn_points_idx: bad sizes N=%lld P1=%lld P2=%lld D=%lld K=%lld", (long long)N,
@@ -335,7 +349,7 @@ int pointops_knn_points_idx(const float* p1, const float* p2, const int64_t* len
       set_error("knn_points_idx: workspace of %zu bytes required (got %zu)", need, workspace_bytes);
       return POINTOPS_EWORKSPACE;
     }
-    const int rc = knn_grid_run(a, norm, workspace);
+    const int rc = knn_grid_run(a, norm, workspace, reuse);
     if (rc != POINTOPS_OK) return rc;
   } else if (v == 0 && knn_wide_supported(D, K) && debug_knob("knn_generic", 0) == 0) {
     // any D / long lists: LDS-transposed queries (POINTOPS_KNN_GENERIC=1 keeps the plain fallback, tests)

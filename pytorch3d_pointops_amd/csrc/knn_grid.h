@@ -33,7 +33,9 @@ int launch_knn_wide(const KnnArgs& a, int norm, void* workspace);
 
 // exact grid search (knn_grid.hip)
 size_t knn_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K);
-int knn_grid_run(const KnnArgs& a, int norm, void* workspace);
+// reuse: 0 = build everything; 1 = the workspace still holds the point side (p2, lengths2) of the previous call;
+// 2 = and the query side (p1, lengths1) too
+int knn_grid_run(const KnnArgs& a, int norm, void* workspace, int reuse = 0);
 
 // ball query through the same grid (knn_grid.hip); see ball_query.hip for the operator
 size_t ball_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2);

@@ -63,7 +63,7 @@ static bool grid_quad_mode(int64_t queries, int kc) {
   return k >= 0 ? k != 0 : queries >= (kc >= 32 ? (1 << 18) : (1 << 20));
 }
 
-int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
+int knn_grid_run(const KnnArgs& a, int norm, void* workspace, int reuse) {
   POINTOPS_REQUIRE(a.N < 65536, "knn_points_idx(grid): batch must be < 65536");
   POINTOPS_REQUIRE(a.P2 <= (1 << 20), "knn_points_idx(grid): P2 must be <= 2^20");
   GridWs ws;
@@ -74,9 +74,13 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace) {
   // the queries are the points (self-KNN): their cell sort is the query order
   b.same = a.p1 == a.p2 && a.l1 == a.l2 && a.P1 == a.P2 && debug_knob("grid_same", 1) != 0;
   b.refine = debug_knob("grid_refine", 1) != 0 ? 1 : 0;
-  int rc = grid_build(a, ws, b);
-  if (rc != POINTOPS_OK) return rc;
-  if (b.refine && (rc = grid_refine(a, ws)) != POINTOPS_OK) return rc;
+  int rc;
+  if (reuse > 0) {  // the point side of the workspace is the previous call's (the caller vouches for it)
+    if ((rc = grid_build_queries(a, ws, b.same, reuse)) != POINTOPS_OK) return rc;
+  } else {
+    if ((rc = grid_build(a, ws, b)) != POINTOPS_OK) return rc;
+    if (b.refine && (rc = grid_refine(a, ws)) != POINTOPS_OK) return rc;
+  }
   const int kc = grid_kc(a.K);
   const bool quad = kc <= 32 && grid_quad_mode(a.N * (int64_t)a.P1, kc);  // (64-slot lists: four of them do not fit a quad's registers)
   switch (a.D) {

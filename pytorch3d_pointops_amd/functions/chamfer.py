@@ -19,7 +19,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
-from ._common import alert_not_deterministic, lengths_max
+from ._common import alert_not_deterministic, full_lengths, lengths_max
 from .knn import knn_gather, knn_points
 
 
@@ -70,7 +70,10 @@ def _handle_pointcloud_input(points, lengths, features):
         raise ValueError("Expected points to be of shape (N, P, D)")
     n, p = points.shape[:2]
     if lengths is None:
-        lengths = torch.full((n,), p, dtype=torch.int64, device=points.device)
+        # (one read-only tensor per (n, p, device): no fill launch per call, and the SAME tensor call after call --
+        # what the grid reuse of `_C.knn_points_idx` recognises a target by)
+        lengths = torch.full((n,), p, dtype=torch.int64, device=points.device) if torch.compiler.is_compiling() \
+            else full_lengths(n, p, points.device)
     else:
         if lengths.ndim != 1 or lengths.shape[0] != n:
             raise ValueError("Expected lengths to be of shape (N,)")

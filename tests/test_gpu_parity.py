@@ -1478,3 +1478,86 @@ def test_reference_example_call_patterns_2(dev):
     p0 = G(u["points"][0], dev)[None]
     kn = knn_points(p0, p0, K=8, return_nn=False)
     same("utils/knn_idx", kn.idx), same("utils/gathered_values", masked_gather(G(u["values"][0], dev)[None], kn.idx))
+
+
+def test_grid_reuse_between_calls(dev, oracle):
+    """`set_grid_cache(True)`: a second query of the same, unmodified target tensor reuses the grid a previous call
+    left in its workspace (pointops_knn_points_idx_reuse levels 1 / 2) -- results bit-identical to the stateless call
+    for new queries, repeated queries, ragged lengths (padded rows are rewritten into the new outputs), a self-query,
+    clouds without a usable grid and the refined-cell path; an IN-PLACE write to the target, a different K or a new
+    target tensor invalidate the cached grid."""
+    import pytorch3d_pointops_amd as po
+    from pytorch3d_pointops_amd import _C
+
+    a = cases.cloud(3501, (4, 9000, 3))
+    b = cases.cloud(3502, (4, 12000, 3))
+    b[1] = (b[1] ** np.float32(4.0)).astype(np.float32)  # density gradient: refined cells, box search
+    b[3, :, :] = b[3, :1, :]                             # one point 12 000 times: no usable grid for this cloud
+    a2 = cases.cloud(3503, (4, 9000, 3))
+    l1, l2 = np.array([9000, 8000, 100, 9000]), np.array([12000, 12000, 5000, 12000])
+    ta, ta2, tb, tl1, tl2 = G(a, dev), G(a2, dev), G(b, dev), G(l1, dev), G(l2, dev)
+
+    def fresh(p1, p2, la, lb, K):
+        po.set_grid_cache(False)
+        try:
+            return _C.knn_points_idx(p1, p2, la, lb, 2, K, 3)
+        finally:
+            po.set_grid_cache(True)
+
+    try:
+        po.set_grid_cache(True)
+        s0 = dict(_C.grid_cache_stats)
+        i0, d0 = _C.knn_points_idx(ta, tb, tl1, tl2, 2, 16, 3)       # miss: builds
+        i1, d1 = _C.knn_points_idx(ta, tb, tl1, tl2, 2, 16, 3)       # both sides cached: no build pass
+        i2, d2 = _C.knn_points_idx(ta2, tb, tl1, tl2, 2, 16, 3)      # new queries: only their sort
+        s1 = dict(_C.grid_cache_stats)
+        assert (s1["miss"] - s0["miss"], s1["both"] - s0["both"], s1["points"] - s0["points"]) == (1, 1, 1)
+        oi, od = oracle.knn_points_idx(a, b, l1, l2, 2, 16)
+        for i, d in ((i0, d0), (i1, d1)):
+            assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(bits(d.cpu().numpy()), bits(od))
+        f2 = fresh(ta2, tb, tl1, tl2, 16)
+        assert torch.equal(i2, f2[0]) and torch.equal(d2, f2[1])
+        # another K is another grid
+        i3, d3 = _C.knn_points_idx(ta, tb, tl1, tl2, 2, 4, 3)
+        assert _C.grid_cache_stats["miss"] == s1["miss"] + 1
+        f3 = fresh(ta, tb, tl1, tl2, 4)
+        assert torch.equal(i3, f3[0]) and torch.equal(d3, f3[1])
+        # an in-place write to the target moves its version counter: the cached grid is not used
+        _C.knn_points_idx(ta, tb, tl1, tl2, 2, 16, 3)
+        tb.mul_(0.5)
+        before = dict(_C.grid_cache_stats)
+        i4, d4 = _C.knn_points_idx(ta, tb, tl1, tl2, 2, 16, 3)
+        assert _C.grid_cache_stats["miss"] == before["miss"] + 1
+        f4 = fresh(ta, tb, tl1, tl2, 16)
+        assert torch.equal(i4, f4[0]) and torch.equal(d4, f4[1]) and not torch.equal(d4, d0)
+        # new lengths tensor for the target (same values elsewhere): a new grid as well
+        tl2b = G(np.array([12000, 6000, 5000, 12000]), dev)
+        i5, d5 = _C.knn_points_idx(ta, tb, tl1, tl2b, 2, 16, 3)
+        f5 = fresh(ta, tb, tl1, tl2b, 16)
+        assert torch.equal(i5, f5[0]) and torch.equal(d5, f5[1])
+        # self-query, then other queries against the same cloud, then the self-query again
+        s_i, s_d = _C.knn_points_idx(tb, tb, tl2, tl2, 2, 8, 3)
+        q_i, q_d = _C.knn_points_idx(ta, tb, tl1, tl2, 2, 8, 3)
+        r_i, r_d = _C.knn_points_idx(tb, tb, tl2, tl2, 2, 8, 3)
+        fs, fq = fresh(tb, tb, tl2, tl2, 8), fresh(ta, tb, tl1, tl2, 8)
+        assert torch.equal(s_i, fs[0]) and torch.equal(s_d, fs[1]) and torch.equal(r_i, fs[0]) and torch.equal(r_d, fs[1])
+        assert torch.equal(q_i, fq[0]) and torch.equal(q_d, fq[1])
+        # the functional API goes through the same cache (chamfer against a fixed target: the target-side grid is kept)
+        from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance
+
+        x = G(cases.cloud(3504, (2, 30000, 3)), dev).requires_grad_(True)
+        y = G(cases.cloud(3505, (2, 30000, 3)), dev)
+        before = dict(_C.grid_cache_stats)
+        l_a, _ = chamfer_distance(x, y)
+        l_b, _ = chamfer_distance(x, y)
+        assert torch.equal(l_a, l_b) and _C.grid_cache_stats["both"] > before["both"]
+        with torch.no_grad():
+            x.add_(0.01)  # an optimiser step: x's grids are rebuilt, y's is reused for the x -> y direction
+        mid = dict(_C.grid_cache_stats)
+        l_c, _ = chamfer_distance(x, y)
+        assert _C.grid_cache_stats["points"] > mid["points"]
+        po.set_grid_cache(False)
+        l_d, _ = chamfer_distance(x, y)
+        assert torch.equal(l_c, l_d)
+    finally:
+        po.set_grid_cache(False)
