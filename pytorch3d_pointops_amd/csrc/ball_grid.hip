@@ -348,7 +348,7 @@ static void ball_run_d(const KnnArgs& a, float radius2, const GridWs& ws, int wg
 // qlist[n * P1 ..] are left -- and 0 for the clouds the index-order scan has to do in full.
 int ball_grid_run(const KnnArgs& a, float radius, void* workspace, const int** flag, const int** qcount,
                   const int** qlist) {
-  POINTOPS_REQUIRE(a.N < 65536 && a.P2 <= (1 << 20) && a.K <= 64 && a.D <= 3, "ball_query(grid): unsupported shape");
+  POINTOPS_REQUIRE(a.N < 65536 && a.P2 <= knn_grid_max_points() && a.K <= 64 && a.D <= 3, "ball_query(grid): unsupported shape");
   GridWs ws;
   grid_carve(&ws, (char*)workspace, a.N, a.P1, a.P2, kBallCellTarget, true);
   ws.ball = 1;

@@ -448,8 +448,9 @@ using namespace pointops;
 static bool ball_grid_candidate(int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K) {
   const long force = debug_knob("ball_grid", -1);  // 0 = never, 1 = whenever the shape allows (tests)
   if (force == 0) return false;
-  if (force == 1) return D <= 3 && K <= 64 && N < 65536 && P2 <= (1 << 20) && N > 0 && P1 > 0 && P2 > 0;
-  return D <= 3 && K <= 64 && N < 65536 && P2 >= 4096 && P2 <= (1 << 20) &&
+  // (its lane kernel keeps run bounds as (first, end) pairs: record indices up to the KNN grid's 2^24 - 16)
+  if (force == 1) return D <= 3 && K <= 64 && N < 65536 && P2 <= knn_grid_max_points() && N > 0 && P1 > 0 && P2 > 0;
+  return D <= 3 && K <= 64 && N < 65536 && P2 >= 4096 && P2 <= knn_grid_max_points() &&
          (double)N * (double)P1 * (double)P2 >= (double)(1LL << 27);
 }
 

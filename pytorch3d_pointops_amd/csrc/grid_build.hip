@@ -236,10 +236,13 @@ __global__ __launch_bounds__(kSetupBlock) void grid_setup_kernel(
           }
           cells *= G[d];
         }
-        if (cells <= (long long)ws.cell_cap) break;
+        // (the two-level sort bins at most kCoarseMax micro-bins of 2^kFineLogMax cells: beyond that, bigger cells)
+        if (cells <= (long long)ws.cell_cap && cells <= ((long long)kCoarseMax << kFineLogMax)) break;
         h *= 1.2599211f;  // halve the cell count
       }
-      if ((long long)G[0] * G[1] * G[2] > (long long)ws.cell_cap) ok = false;
+      if ((long long)G[0] * G[1] * G[2] > (long long)ws.cell_cap ||
+          (long long)G[0] * G[1] * G[2] > ((long long)kCoarseMax << kFineLogMax))
+        ok = false;
     }
     for (int d = 0; d < 3; ++d) {
       g.lo[d] = lo[d];

@@ -283,8 +283,8 @@ int pointops_knn_check_version(int version, int64_t D, int64_t K) {
 }
 
 static int choose_version(int version, int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K) {
-  // scan chunk table limit; clouds ride on gridDim.y in the build passes
-  const bool grid_ok = pointops_knn_check_version(3, D, K) && P2 <= (1LL << 20) && N < 65536;
+  // clouds of up to 2^24 - 16 points (24-bit record indices in the searches' run words); any batch size (slices)
+  const bool grid_ok = pointops_knn_check_version(3, D, K) && P2 <= knn_grid_max_points();
   if (version == 3 && !grid_ok) version = -1;
   if (version >= 0 && version <= 3 && pointops_knn_check_version(version, D, K)) return version;
   // auto: the grid only pays once the all-pairs scan is longer than the grid's floor of ~12 launches (0.08-0.1 ms);

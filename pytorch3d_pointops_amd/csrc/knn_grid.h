@@ -31,7 +31,8 @@ void knn_merge_partials(const KnnArgs& a, int S, const void* workspace);
 bool knn_wide_supported(int64_t D, int64_t K);
 int launch_knn_wide(const KnnArgs& a, int norm, void* workspace);
 
-// exact grid search (knn_grid.hip)
+// exact grid search (knn_grid.hip); clouds of up to knn_grid_max_points() points, any batch size
+int64_t knn_grid_max_points();
 size_t knn_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K);
 // reuse: 0 = build everything; 1 = the workspace still holds the point side (p2, lengths2) of the previous call;
 // 2 = and the query side (p1, lengths1) too

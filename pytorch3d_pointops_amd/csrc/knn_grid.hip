@@ -50,7 +50,7 @@ static float knn_cell_target(int K) {
 }
 
 size_t knn_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K) {
-  return grid_carve(nullptr, nullptr, N, P1, P2, knn_cell_target((int)K));
+  return grid_carve(nullptr, nullptr, N < 32768 ? N : 32768, P1, P2, knn_cell_target((int)K));  // (kGridBatchSlice)
 }
 
 static bool grid_quad_mode(int64_t queries, int kc) {
@@ -63,9 +63,13 @@ static bool grid_quad_mode(int64_t queries, int kc) {
   return k >= 0 ? k != 0 : queries >= (kc >= 32 ? (1 << 18) : (1 << 20));
 }
 
-int knn_grid_run(const KnnArgs& a, int norm, void* workspace, int reuse) {
-  POINTOPS_REQUIRE(a.N < 65536, "knn_points_idx(grid): batch must be < 65536");
-  POINTOPS_REQUIRE(a.P2 <= (1 << 20), "knn_points_idx(grid): P2 must be <= 2^20");
+// clouds per launch: the build passes and the fallback searches put the cloud on blockIdx.y (< 65536); a bigger
+// batch is searched in slices of this many clouds through the same workspace, one after the other
+constexpr int64_t kGridBatchSlice = 32768;
+
+int64_t knn_grid_max_points() { return kGridMaxPointsBig; }
+
+static int knn_grid_run_slice(const KnnArgs& a, int norm, void* workspace, int reuse) {
   GridWs ws;
   const float c = knn_cell_target(a.K);
   grid_carve(&ws, (char*)workspace, a.N, a.P1, a.P2, c);
@@ -83,10 +87,12 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace, int reuse) {
   }
   const int kc = grid_kc(a.K);
   const bool quad = kc <= 32 && grid_quad_mode(a.N * (int64_t)a.P1, kc);  // (64-slot lists: four of them do not fit a quad's registers)
+  // run words of the lane / box searches: 21-bit record indices, or 24-bit ones for the biggest clouds
+  const bool big = a.P2 > kGridMaxPoints || debug_knob("grid_big", 0) != 0;
   switch (a.D) {
-    case 1: grid_search_d1(a, ws, norm, kc, quad); break;
-    case 2: grid_search_d2(a, ws, norm, kc, quad); break;
-    default: grid_search_d3(a, ws, norm, kc, quad); break;
+    case 1: (big ? grid_search_d1w : grid_search_d1)(a, ws, norm, kc, quad); break;
+    case 2: (big ? grid_search_d2w : grid_search_d2)(a, ws, norm, kc, quad); break;
+    default: (big ? grid_search_d3w : grid_search_d3)(a, ws, norm, kc, quad); break;
   }
   rc = check_launch("knn_points_idx(grid)");
   if (rc != POINTOPS_OK) return rc;
@@ -99,12 +105,32 @@ int knn_grid_run(const KnnArgs& a, int norm, void* workspace, int reuse) {
   return check_launch("knn_points_idx(grid fallback)");
 }
 
+int knn_grid_run(const KnnArgs& a, int norm, void* workspace, int reuse) {
+  POINTOPS_REQUIRE(a.P2 <= kGridMaxPointsBig, "knn_points_idx(grid): P2 must be <= 2^24 - 16");
+  if (a.N <= kGridBatchSlice) return knn_grid_run_slice(a, norm, workspace, reuse);
+  // more clouds than a launch takes: slices share the workspace (stream order), so nothing of it outlives the call
+  for (int64_t n0 = 0; n0 < a.N; n0 += kGridBatchSlice) {
+    KnnArgs s = a;
+    const bool same_pts = a.p1 == a.p2, same_len = a.l1 == a.l2;
+    s.N = a.N - n0 < kGridBatchSlice ? a.N - n0 : kGridBatchSlice;
+    s.p1 = a.p1 + n0 * (int64_t)a.P1 * a.D;
+    s.p2 = same_pts ? s.p1 : a.p2 + n0 * (int64_t)a.P2 * a.D;
+    s.l1 = a.l1 + n0;
+    s.l2 = same_len ? s.l1 : a.l2 + n0;
+    s.idxs = a.idxs + n0 * (int64_t)a.P1 * a.K;
+    s.dists = a.dists + n0 * (int64_t)a.P1 * a.K;
+    const int rc = knn_grid_run_slice(s, norm, workspace, 0);
+    if (rc != POINTOPS_OK) return rc;
+  }
+  return POINTOPS_OK;
+}
+
 }  // namespace pointops
 
 extern "C" int pointops_knn_grid_fallback_counts(const void* workspace, int64_t N, int64_t P1, int64_t P2,
                                                  int64_t K, int32_t* counts, void* stream) {
   using namespace pointops;
-  POINTOPS_REQUIRE(workspace != nullptr && counts != nullptr && N > 0, "knn_grid_fallback_counts: bad arguments");
+  POINTOPS_REQUIRE(workspace != nullptr && counts != nullptr && N > 0 && N <= 32768, "knn_grid_fallback_counts: bad arguments");
   GridWs ws;
   grid_carve(&ws, (char*)workspace, N, P1, P2, knn_cell_target((int)K));
   if (hipMemcpyAsync(counts + N, ws.fb2_count, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice,
@@ -146,7 +172,7 @@ __global__ void grid_stats_kernel(GridWs ws, int N, int32_t* __restrict__ stats)
 extern "C" int pointops_knn_grid_stats(const void* workspace, int64_t N, int64_t P1, int64_t P2, int64_t K,
                                        int32_t* stats, void* stream) {
   using namespace pointops;
-  POINTOPS_REQUIRE(workspace != nullptr && stats != nullptr && N > 0, "knn_grid_stats: bad arguments");
+  POINTOPS_REQUIRE(workspace != nullptr && stats != nullptr && N > 0 && N <= 32768, "knn_grid_stats: bad arguments");
   GridWs ws;
   grid_carve(&ws, (char*)workspace, N, P1, P2, knn_cell_target((int)K));
   hipLaunchKernelGGL(grid_stats_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, ws, (int)N,

@@ -29,12 +29,13 @@ constexpr int kBoxMaxRecords = 3072;  // a lane never walks more than this: a bi
                                       // dense cell from outside) belongs to the wave-per-query search, whose 64 lanes
                                       // share it -- one lane walking 32 k records holds its whole wave for milliseconds
 
-template <int D, int KC, int NORM>
+template <int D, int KC, int NORM, int RB>
 __global__ __launch_bounds__(kGridWave) void knn_grid_box_kernel(
     const float* __restrict__ p1, GridWs ws, int P1, int P2, int K, int* __restrict__ out_count,
     int* __restrict__ out_list, int64_t* __restrict__ idxs, float* __restrict__ dists) {
   constexpr bool kUseQueue = LaneCfg<KC>::kUseQueue;
   constexpr int kQueueCap = LaneCfg<KC>::kQueueLds;
+  constexpr int kRunBits = RB, kRunMax = (1 << RB) - 1;
   __shared__ double s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
   __shared__ unsigned s_rows[kBoxRows + 1][kGridWave];
   const int n = blockIdx.y;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_box_kernel(
       // ---- walk + select (list restarted for every attempt), certify against the box faces
       top.init();
       const unsigned thr0 = seed_threshold(lb, false);
-      lane_walk<D, KC, NORM, kBoxRows>((const char*)sp, rows, lane, s_queue, q[0], q[1], q[2], thr0, top);
+      lane_walk<D, KC, NORM, kBoxRows, RB>((const char*)sp, rows, lane, s_queue, q[0], q[1], q[2], thr0, top);
       if (!done && !overflow) {
         const unsigned kth_bits = top.kth_bits(K);
         if (kth_bits < 0x7f800000u && __uint_as_float(kth_bits) < lb) {
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(kGridWave) void knn_grid_box_kernel(
   }
 }
 
-template <int D, int KC, int NORM>
+template <int D, int KC, int NORM, int RB>
 static void launch_grid_box(const KnnArgs& a, const GridWs& ws, bool quad) {
   // one 64-query chunk of the box list per workgroup where the grid allows it: the lanes' work differs by orders of
   // magnitude on the clouds that need this pass (u^4 cloud 4.63 -> 4.10 ms, half_in_cluster 3.20 -> 2.53 ms against one
@@ -198,7 +199,7 @@ static void launch_grid_box(const KnnArgs& a, const GridWs& ws, bool quad) {
   // workgroups and 4 KB more LDS cost more than the idle lanes of the late radii)
   int64_t wx = a.P1 / kGridWave;
   wx = wx < 8 ? 8 : wx > 1024 ? 1024 : wx;
-  hipLaunchKernelGGL((knn_grid_box_kernel<D, KC, NORM>), dim3((unsigned)wx, (unsigned)a.N), dim3(kGridWave), 0, a.stream,
+  hipLaunchKernelGGL((knn_grid_box_kernel<D, KC, NORM, RB>), dim3((unsigned)wx, (unsigned)a.N), dim3(kGridWave), 0, a.stream,
                      a.p1, ws, a.P1, a.P2, a.K, quad ? ws.fb3_count : ws.fb_count, quad ? ws.fb3_list : ws.fb_list, a.idxs,
                      a.dists);
 }

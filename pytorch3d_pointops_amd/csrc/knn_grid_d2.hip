@@ -5,8 +5,8 @@
 namespace pointops {
 
 void grid_search_d2(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool quad) {
-  if (norm == 1) grid_search_dispatch<2, 1>(a, ws, kc, quad);
-  else grid_search_dispatch<2, 2>(a, ws, kc, quad);
+  if (norm == 1) grid_search_dispatch<2, 1, kRunBitsStd>(a, ws, kc, quad);
+  else grid_search_dispatch<2, 2, kRunBitsStd>(a, ws, kc, quad);
 }
 
 }  // namespace pointops

@@ -76,9 +76,14 @@ struct LaneCfg {
 // is always zero); on return `top` holds the KC best of those records (see the comment above the lane kernel).
 // `s_queue` is the wave's 16 x 64 queue, every slot holding the empty key on entry and on return.
 // ---------------------------------------------------------------------------
-constexpr int kRunBits = 11, kRunMax = (1 << kRunBits) - 1;
+// Run words: first record << RB | length.  RB = 11 (runs of up to 2047 records, clouds of up to 2^21 - 16 points) is what
+// every kernel below was tuned with; RB = 8 (runs of up to 255 records -- a longer run sends its query to the box
+// search, which splits runs -- clouds of up to 2^24 - 16 points) exists so that big clouds do not fall back to the
+// all-pairs scan (knn_grid_d*w.hip instantiate it).
+constexpr int kRunBitsStd = 11, kRunBitsBig = 8;
+constexpr int64_t kGridMaxPoints = (1LL << (32 - kRunBitsStd)) - 16, kGridMaxPointsBig = (1LL << (32 - kRunBitsBig)) - 16;
 
-template <int D, int KC, int NORM, int ROWS>
+template <int D, int KC, int NORM, int ROWS, int RB>
 __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const unsigned* rows, int lane,
                                           double* s_queue, float qx, float qy, float qz, unsigned thr0,
                                           TopKF64<KC>& top) {
@@ -89,6 +94,7 @@ __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const un
   constexpr int kSub = Cfg::kSub;
   constexpr int G = Cfg::kGroup;
   constexpr int kGroupBytes = G * 16;
+  constexpr int kRunBits = RB, kRunMax = (1 << RB) - 1;
   double* const qbase = s_queue + lane;
   int rowi = lane + 2 * kGridWave;  // entry of `rows` after the prefetched one
   const int rowlast = lane + ROWS * kGridWave;
@@ -193,7 +199,7 @@ __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const un
 
 // (second launch bound = waves per SIMD the compiler has to leave room for: the 64-slot list needs 261 registers
 // without it, five more than two waves allow)
-template <int D, int KC, int NORM>
+template <int D, int KC, int NORM, int RB>
 __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kernel(
     const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const int* __restrict__ chunk_prefix,
     const float* __restrict__ edges, const int* __restrict__ cell_start, const float4* __restrict__ sorted,
@@ -205,6 +211,7 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
   constexpr int kQueueCap = Cfg::kQueueLds;
   constexpr int kSub = Cfg::kSub;
   constexpr int G = Cfg::kGroup;
+  constexpr int kRunBits = RB, kRunMax = (1 << RB) - 1;
   static_assert(G % kSub == 0 && G <= kSortedPad, "group geometry");
   __shared__ double s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
   // per-lane list of its non-empty runs, one word each: first record << 11 | length (<= 2047; a lane with a longer
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
     }
     TopKF64<KC> top;
     top.init();
-    lane_walk<D, KC, NORM, kLaneRows>((const char*)sp, rows, lane, s_queue, qx, qy, qz, thr0, top);
+    lane_walk<D, KC, NORM, kLaneRows, RB>((const char*)sp, rows, lane, s_queue, qx, qy, qz, thr0, top);
 
     const unsigned kth_bits = top.kth_bits(K);  // the K-th best, not the list's last slot
     const bool full = kth_bits < 0x7f800000u;
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(kWaveKernelBlock) void knn_grid_wave_kernel(
 // ---------------------------------------------------------------------------
 // launches of one (D, NORM): lane search, then the exact fallbacks for what it could not certify
 // ---------------------------------------------------------------------------
-template <int D, int KC, int NORM>
+template <int D, int KC, int NORM, int RB>
 static void launch_grid_box(const KnnArgs& a, const GridWs& ws, bool quad);  // knn_grid_box.h
 
 // 64-slot lists have no quad pass: their uncertified queries take the box search when the batch sends it enough of them
@@ -707,7 +714,7 @@ static inline bool long_lists_to_box(const KnnArgs& a) {
   return k >= 0 ? k != 0 : a.N * (int64_t)a.P1 >= (3LL << 19);
 }
 
-template <int D, int KC, int NORM>
+template <int D, int KC, int NORM, int RB>
 static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
   // One wave64 per workgroup and ONE chunk of 64 queries per workgroup where the launch allows it (a multiple of 8: the
   // XCD-aware order): the hardware's workgroup dispatcher then balances the chunks (cfg2, ms per step: 3 840 resident
@@ -715,7 +722,7 @@ static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
   int64_t chunks = (int64_t)a.N * ceil_div(a.P1, kGridWave);
   chunks = (chunks + 7) / 8 * 8;
   const int wgs = (int)(chunks < 2048 ? 2048 : (chunks > (1 << 20) ? (1 << 20) : chunks));
-  hipLaunchKernelGGL((knn_grid_lane_kernel<D, KC, NORM>), dim3((unsigned)wgs), dim3(kGridWave), 0, a.stream, a.p1,
+  hipLaunchKernelGGL((knn_grid_lane_kernel<D, KC, NORM, RB>), dim3((unsigned)wgs), dim3(kGridWave), 0, a.stream, a.p1,
                      (const GridCloud*)ws.cloud, (const int*)ws.chunk_prefix, (const float*)ws.edges,
                      (const int*)ws.cell_start, (const float4*)ws.sorted, (const float4*)ws.qsorted, ws.fb_count,
                      ws.fb_list, ws.fb_kth, ws.box_count, ws.box_list, kDeferFactor * refine_threshold(ws.c_target),
@@ -729,7 +736,7 @@ static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
                        (const unsigned*)ws.fb_kth, ws.fb3_count, ws.fb3_list, ws.box_count, ws.box_list, ws.cell_cap, a.P1,
                        a.P2, a.K, a.idxs, a.dists);
   }
-  launch_grid_box<D, KC, NORM>(a, ws, quad);  // over-full neighbourhoods (appends what it cannot certify)
+  launch_grid_box<D, KC, NORM, RB>(a, ws, quad);  // over-full neighbourhoods (appends what it cannot certify)
   hipLaunchKernelGGL((knn_grid_wave_kernel<D, KC, NORM>), dim3(kWaveKernelWgsPerCloud, (unsigned)a.N),
                      dim3(kWaveKernelBlock), 0, a.stream, a.p1, (const GridCloud*)ws.cloud, (const float*)ws.edges,
                      (const int*)ws.cell_start, (const float4*)ws.sorted,
@@ -737,22 +744,26 @@ static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
                      ws.fb2_count, ws.fb2_list, ws.cell_cap, a.P1, a.P2, a.K, quad ? 4 : 2, a.idxs, a.dists);
 }
 
-template <int D, int NORM>
+template <int D, int NORM, int RB>
 void grid_search_dispatch(const KnnArgs& a, const GridWs& ws, int kc, bool quad) {
   switch (kc) {
-    case 1: launch_grid_passes<D, 1, NORM>(a, ws, quad); break;
-    case 2: launch_grid_passes<D, 2, NORM>(a, ws, quad); break;
-    case 4: launch_grid_passes<D, 4, NORM>(a, ws, quad); break;
-    case 8: launch_grid_passes<D, 8, NORM>(a, ws, quad); break;
-    case 16: launch_grid_passes<D, 16, NORM>(a, ws, quad); break;
-    case 32: launch_grid_passes<D, 32, NORM>(a, ws, quad); break;
-    default: launch_grid_passes<D, 64, NORM>(a, ws, false); break;
+    case 1: launch_grid_passes<D, 1, NORM, RB>(a, ws, quad); break;
+    case 2: launch_grid_passes<D, 2, NORM, RB>(a, ws, quad); break;
+    case 4: launch_grid_passes<D, 4, NORM, RB>(a, ws, quad); break;
+    case 8: launch_grid_passes<D, 8, NORM, RB>(a, ws, quad); break;
+    case 16: launch_grid_passes<D, 16, NORM, RB>(a, ws, quad); break;
+    case 32: launch_grid_passes<D, 32, NORM, RB>(a, ws, quad); break;
+    default: launch_grid_passes<D, 64, NORM, RB>(a, ws, false); break;
   }
 }
 
-// one translation unit per point dimension (knn_grid_d1/2/3.hip)
+// one translation unit per point dimension and run-word geometry (knn_grid_d1/2/3.hip: clouds of up to
+// kGridMaxPoints points; knn_grid_d1/2/3w.hip: bigger ones)
 void grid_search_d1(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool quad);
 void grid_search_d2(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool quad);
 void grid_search_d3(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool quad);
+void grid_search_d1w(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool quad);
+void grid_search_d2w(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool quad);
+void grid_search_d3w(const KnnArgs& a, const GridWs& ws, int norm, int kc, bool quad);
 
 }  // namespace pointops

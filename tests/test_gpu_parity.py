@@ -9,6 +9,7 @@ or tree reductions reorder sums (grad_p2, chamfer losses).
 import hashlib
 import json
 import os
+import time
 
 import numpy as np
 import pytest
@@ -1561,3 +1562,72 @@ def test_grid_reuse_between_calls(dev, oracle):
         assert torch.equal(l_c, l_d)
     finally:
         po.set_grid_cache(False)
+
+
+def _bruteforce_rows(q, pts, K):
+    """(idx, dists) of the K nearest of `pts` for every row of `q` by a dense torch distance table with the kernels'
+    expression ((dx*dx + dy*dy) + dz*dz) and lexicographic (dist, idx) order (stable sort)."""
+    d = q[:, None, :] - pts[None, :, :]
+    d = d * d
+    full = (d[..., 0] + d[..., 1]) + d[..., 2]
+    val, idx = torch.sort(full, dim=1, stable=True)
+    return idx[:, :K], val[:, :K]
+
+
+@pytest.mark.parametrize("P,K", [(2_000_000, 16), (5_000_000, 8)])
+def test_knn_single_huge_cloud(dev, P, K):
+    """One cloud of 2 M points (the 21-bit run words) and one of 5 M (the 24-bit run words of knn_grid_d3w.hip: round 2
+    refused clouds over 2^20 points and fell back to the all-pairs scan, ~1 s for 2 M x 2 M): self-excluded p1 != p2
+    query through the grid, sampled rows against a brute-force torch distance table, and sortedness / range
+    properties of every row."""
+    from pytorch3d_pointops_amd import _C, synth
+
+    p1 = G(synth.uniform_f32(3601, (1, P, 3)), dev)
+    p2 = G(synth.uniform_f32(3602, (1, P, 3)), dev)
+    L = torch.full((1,), P, dtype=torch.int64, device=dev)
+    assert _C._lib.pointops_knn_uses_grid(1, P, P, 3, K, -1) == 1
+    idx, d = _C.knn_points_idx(p1, p2, L, L, 2, K, -1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        idx, d = _C.knn_points_idx(p1, p2, L, L, 2, K, -1)
+    torch.cuda.synchronize()
+    print(f"knn {P} x {P} K={K}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms per call")
+    rows = torch.arange(17, P, P // 61, device=dev)
+    bi, bd = _bruteforce_rows(p1[0, rows], p2[0], K)
+    assert torch.equal(idx[0, rows], bi) and torch.equal(d[0, rows], bd)
+    assert bool((d[0, :, 1:] >= d[0, :, :-1]).all()) and bool((idx >= 0).all()) and bool((idx < P).all())
+    # every row's distances are the distances to the points it names
+    sel = torch.arange(0, P, 1009, device=dev)
+    g = p2[0][idx[0, sel]] - p1[0, sel][:, None, :]
+    g = g * g
+    assert torch.equal((g[..., 0] + g[..., 1]) + g[..., 2], d[0, sel])
+
+
+def test_knn_grid_wide_run_words_and_batch_slices(dev, oracle, monkeypatch):
+    """(a) The 24-bit / 8-bit run words (clouds over 2^21 points) forced on small adversarial clouds -- runs longer than
+    255 records must reach the box search -- against the oracle; (b) more clouds than one launch takes (> 32768: the
+    batch is searched in slices through one workspace) against the brute-force family."""
+    from pytorch3d_pointops_amd import _C
+
+    a = cases.cloud(3701, (3, 6000, 3))
+    b = cases.cloud(3702, (3, 20000, 3))
+    b[1, :8000] = b[1, :8000] * np.float32(2e-3) + np.float32(0.3)  # a cluster: runs of thousands of records
+    b[2] = (b[2] ** np.float32(3.0)).astype(np.float32)
+    l1, l2 = np.array([6000, 6000, 777]), np.array([20000, 20000, 15000])
+    monkeypatch.setenv("POINTOPS_DEBUG", "grid_big=1")
+    for K, norm in ((16, 2), (3, 1), (40, 2)):
+        idx, d, st = _C.knn_grid_stats(G(a, dev), G(b, dev), G(l1, dev), G(l2, dev), norm, K)
+        oi, od = oracle.knn_points_idx(a, b, l1, l2, norm, K)
+        assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(bits(d.cpu().numpy()), bits(od)), (K, norm)
+        assert int(st.cpu().numpy()[1, 8]) > 0  # the cluster's queries went to the box search
+    monkeypatch.delenv("POINTOPS_DEBUG")
+    N = 33000
+    p = G(cases.cloud(3703, (N, 48, 3)), dev)
+    q = G(cases.cloud(3704, (N, 20, 3)), dev)
+    lp = torch.full((N,), 48, dtype=torch.int64, device=dev)
+    lq = torch.full((N,), 20, dtype=torch.int64, device=dev)
+    lp[::7] = 5
+    i3, d3 = _C.knn_points_idx(q, p, lq, lp, 2, 4, 3)
+    i2, d2 = _C.knn_points_idx(q, p, lq, lp, 2, 4, 2)
+    assert torch.equal(i3, i2) and torch.equal(d3, d2)
