@@ -243,7 +243,7 @@ def knn_grid_fallback_counts(p1, p2, lengths1, lengths2, norm: int, K: int):
     N, P1, D = p1.shape
     P2 = p2.shape[1]
     if not knn_check_version(3, D, K):
-        raise RuntimeError("grid family needs D <= 3 and K <= 64")
+        raise RuntimeError("grid family needs D <= 3 and K <= 128")
     with torch.cuda.device(dev):
         idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
         dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
@@ -270,7 +270,7 @@ def knn_grid_stats(p1, p2, lengths1, lengths2, norm: int, K: int):
     N, P1, D = p1.shape
     P2 = p2.shape[1]
     if not knn_check_version(3, D, K):
-        raise RuntimeError("grid family needs D <= 3 and K <= 64")
+        raise RuntimeError("grid family needs D <= 3 and K <= 128")
     with torch.cuda.device(dev):
         idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
         dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)

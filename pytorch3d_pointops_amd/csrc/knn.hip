@@ -275,10 +275,11 @@ int pointops_knn_check_version(int version, int64_t D, int64_t K) {
   //   0 any D, any K: LDS-transposed queries with register (K <= 32) or LDS lists (knn_wide.hip);
   //     beyond the LDS budget the plain generic kernel (list kept in the output rows)
   //   1, 2 register top-K brute-force scan (D in [1,8], K in [1,32])
-  //   3 exact grid-pruned search + brute-force fallback (D in [1,3], K in [1,64])
+  //   3 exact grid-pruned search + brute-force fallback (D in [1,3], K in [1,128]: lane-private lists up to 64,
+  //     wave-per-query sorting above)
   if (version == 0) return 1;
   if (version == 1 || version == 2) return (D >= 1 && D <= 8 && K >= 1 && K <= 32) ? 1 : 0;
-  if (version == 3) return (D >= 1 && D <= 3 && K >= 1 && K <= 64) ? 1 : 0;
+  if (version == 3) return (D >= 1 && D <= 3 && K >= 1 && K <= 128) ? 1 : 0;
   return 0;
 }
 

@@ -31,6 +31,11 @@ void knn_merge_partials(const KnnArgs& a, int S, const void* workspace);
 bool knn_wide_supported(int64_t D, int64_t K);
 int launch_knn_wide(const KnnArgs& a, int norm, void* workspace);
 
+// long lists, 64 < K <= 128: wave-per-query search of the 3x3x3 cube with one 2048-key sort (knn_grid_wsort.hip);
+// uncertified queries are appended to ws.fb2_list
+struct GridWs;
+void grid_search_wsort(const KnnArgs& a, const GridWs& ws, int norm);
+
 // exact grid search (knn_grid.hip); clouds of up to knn_grid_max_points() points, any batch size
 int64_t knn_grid_max_points();
 size_t knn_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K);

@@ -77,13 +77,23 @@ static int knn_grid_run_slice(const KnnArgs& a, int norm, void* workspace, int r
   b.c_target = c;
   // the queries are the points (self-KNN): their cell sort is the query order
   b.same = a.p1 == a.p2 && a.l1 == a.l2 && a.P1 == a.P2 && debug_knob("grid_same", 1) != 0;
-  b.refine = debug_knob("grid_refine", 1) != 0 ? 1 : 0;
+  b.refine = (debug_knob("grid_refine", 1) != 0 && a.K <= 64) ? 1 : 0;  // (the long-list search walks whole cells)
   int rc;
   if (reuse > 0) {  // the point side of the workspace is the previous call's (the caller vouches for it)
     if ((rc = grid_build_queries(a, ws, b.same, reuse)) != POINTOPS_OK) return rc;
   } else {
     if ((rc = grid_build(a, ws, b)) != POINTOPS_OK) return rc;
     if (b.refine && (rc = grid_refine(a, ws)) != POINTOPS_OK) return rc;
+  }
+  if (a.K > 64) {  // long lists: a wave per query sorts its cube's candidates (knn_grid_wsort.hip)
+    grid_search_wsort(a, ws, norm);
+    rc = check_launch("knn_points_idx(grid, long lists)");
+    if (rc != POINTOPS_OK) return rc;
+    KnnArgs fa = a;
+    fa.qlist = ws.fb2_list;
+    fa.qcount = ws.fb2_count;
+    if ((rc = launch_knn_wide(fa, norm, nullptr)) != POINTOPS_OK) return rc;
+    return check_launch("knn_points_idx(grid fallback)");
   }
   const int kc = grid_kc(a.K);
   const bool quad = kc <= 32 && grid_quad_mode(a.N * (int64_t)a.P1, kc);  // (64-slot lists: four of them do not fit a quad's registers)

@@ -1631,3 +1631,52 @@ def test_knn_grid_wide_run_words_and_batch_slices(dev, oracle, monkeypatch):
     i3, d3 = _C.knn_points_idx(q, p, lq, lp, 2, 4, 3)
     i2, d2 = _C.knn_points_idx(q, p, lq, lp, 2, 4, 2)
     assert torch.equal(i3, i2) and torch.equal(d3, d2)
+
+
+@pytest.mark.parametrize("K,norm,D", [(65, 2, 3), (100, 2, 3), (128, 2, 3), (100, 1, 3), (96, 2, 2), (80, 2, 1)])
+def test_knn_grid_wave_sort_long_lists(dev, oracle, K, norm, D):
+    """64 < K <= 128 through the grid family (knn_grid_wsort.hip: a wave per query, 2048-key sorts of its cube's
+    candidates): ragged clouds, a cluster whose cubes hold more records than the kernel streams (those queries take the
+    all-pairs list; smaller overflows are sorted chunk by chunk), a cloud shorter than K, duplicated points (ties
+    resolved by index), against the oracle and the brute-force family."""
+    from pytorch3d_pointops_amd import _C
+
+    p1 = cases.cloud(3801, (4, 1500, D))
+    p2 = cases.cloud(3802, (4, 30000, D))
+    p2[1, :20000] = p2[1, :20000] * np.float32(3e-3) + np.float32(0.4)  # cluster: cubes with > 16384 records
+    p2[2, 1::2] = p2[2, ::2]  # every point twice: ties in every list
+    l1 = np.array([1500, 1500, 1500, 40])
+    l2 = np.array([30000, 30000, 21000, K - 7])
+    args = (G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm, K)
+    idx, d, counts = _C.knn_grid_fallback_counts(*args)
+    oi, od = oracle.knn_points_idx(p1, p2, l1, l2, norm, K)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(bits(d.cpu().numpy()), bits(od))
+    counts = counts.cpu().numpy()
+    assert 0 < counts[1, 1], counts  # the cluster's neighbourhood exceeds the stream: all-pairs list
+    if norm == 2 and D == 3:  # (cells are sized for 3-D Euclidean balls: 0.4 K points)
+        assert counts[1, 0] == 0, counts  # every query of the uniform cloud is certified by its radius-1 or -2 cube
+    i0, d0 = _C.knn_points_idx(*args, 0)
+    assert torch.equal(i0, idx) and torch.equal(d0, d)
+
+
+def test_knn_long_list_big_cloud(dev):
+    """One 300 000-point cloud, K = 100 (round 2: the all-pairs scan, 9e10 pairs): sampled rows against a brute-force
+    torch distance table, sortedness of every row."""
+    from pytorch3d_pointops_amd import _C, synth
+
+    P, K = 300_000, 100
+    p1 = G(synth.uniform_f32(3811, (1, P, 3)), dev)
+    p2 = G(synth.uniform_f32(3812, (1, P, 3)), dev)
+    L = torch.full((1,), P, dtype=torch.int64, device=dev)
+    idx, d = _C.knn_points_idx(p1, p2, L, L, 2, K, -1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        idx, d = _C.knn_points_idx(p1, p2, L, L, 2, K, -1)
+    torch.cuda.synchronize()
+    print(f"knn {P} x {P} K={K}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms per call")
+    rows = torch.arange(5, P, P // 97, device=dev)
+    bi, bd = _bruteforce_rows(p1[0, rows], p2[0], K)
+    assert torch.equal(idx[0, rows], bi) and torch.equal(d[0, rows], bd)
+    assert bool((d[0, :, 1:] >= d[0, :, :-1]).all()) and bool((idx >= 0).all()) and bool((idx < P).all())

@@ -25,6 +25,12 @@ elif op == "fps":
     Kt = torch.full((B,), 1024, dtype=torch.int64, device=dev)
     S = torch.zeros((B,), dtype=torch.int64, device=dev)
     fn = lambda: _C.sample_farthest_points(pts, L, Kt, S)  # noqa: E731
+elif op == "knn_k100":
+    B, P = 1, 300000
+    p1 = torch.from_numpy(synth.uniform_f32(3811, (B, P, 3))).to(dev)
+    p2 = torch.from_numpy(synth.uniform_f32(3812, (B, P, 3))).to(dev)
+    L = torch.full((B,), P, dtype=torch.int64, device=dev)
+    fn = lambda: _C.knn_points_idx(p1, p2, L, L, 2, 100, -1)  # noqa: E731
 else:
     B, P = 32, 65536
     p1 = torch.from_numpy(synth.uniform_f32(11, (B, P, 3))).to(dev)
