@@ -9,10 +9,10 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 10 --warmup 3 > $OUT/bench_under_rocprof.json 2> /dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample-queries 0 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample-queries 0 > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample-queries 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 10 --warmup 3 --reuse-steps 0 > $OUT/bench_under_rocprof.json 2> /dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample-queries 0 --reuse-steps 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample-queries 0 --reuse-steps 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample-queries 0 --reuse-steps 0 > /dev/null 2>&1
 cd $R
 python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write 4 $OUT/pmc_traffic.json
 python tools/sq_counters.py $OUT/pmc_sq 4 $OUT/sq_counters.json

@@ -25,6 +25,20 @@ elif op == "fps":
     Kt = torch.full((B,), 1024, dtype=torch.int64, device=dev)
     S = torch.zeros((B,), dtype=torch.int64, device=dev)
     fn = lambda: _C.sample_farthest_points(pts, L, Kt, S)  # noqa: E731
+elif op in ("knn_reuse", "knn_reuse_new_queries"):  # cfg2 with the opt-in grid reuse: same target, same / alternating queries
+    import pytorch3d_pointops_amd as po
+
+    B, P = 32, 65536
+    p1 = torch.from_numpy(synth.uniform_f32(11, (B, P, 3))).to(dev)
+    p1b = p1.flip(0).contiguous()
+    p2 = torch.from_numpy(synth.uniform_f32(12, (B, P, 3))).to(dev)
+    L = torch.full((B,), P, dtype=torch.int64, device=dev)
+    po.set_grid_cache(True)
+    qs = [p1, p1b] if op == "knn_reuse_new_queries" else [p1, p1]
+
+    def fn():
+        qs.reverse()
+        return _C.knn_points_idx(qs[0], p2, L, L, 2, 16, -1)
 elif op == "knn_k100":
     B, P = 1, 300000
     p1 = torch.from_numpy(synth.uniform_f32(3811, (B, P, 3))).to(dev)
