@@ -154,6 +154,11 @@ def main():
             emit(f"knn_points_backward B=32 N=65536 K=16 [{mode}]", ms, mn, algo_GBs=algo / ms / 1e6,
                  scatter_adds_per_s=Bb * Pb * Kb * 3 / ms * 1e3)
         del os.environ["POINTOPS_DEBUG"]
+        ms, mn = timeit(lambda: _C.knn_points_backward(a, c, Lb, Lb, idx, 2, gd, deterministic=True), warmup=1, iters=5)
+        emit("knn_points_backward B=32 N=65536 K=16 [deterministic: inverted table]", ms, mn, algo_GBs=algo / ms / 1e6)
+        go = torch.from_numpy(synth.uniform_f32(84, (Bb, Pb, Kb, 3))).to(dev)
+        ms, mn = timeit(lambda: _C.gather_neighbors_backward(go, idx, None, Pb, deterministic=True), warmup=1, iters=5)
+        emit("knn_gather backward B=32 N=65536 K=16 U=3 [deterministic: inverted table]", ms, mn)
         for (b, n, k) in ((1, 65536, 16), (4, 16384, 16), (8, 65536, 1)):
             a2, c2 = a[:b, :n].contiguous(), c[:b, :n].contiguous()
             L2 = torch.full((b,), n, dtype=torch.int64, device=dev)
