@@ -130,6 +130,23 @@ def _i64c(t, name):
     return t.contiguous()
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(dev):
+    """Device guard for the launches: torch.cuda.device(dev) only when `dev` is not already current (its constructor,
+    __enter__ and __exit__ cost ~4 us of a small call; the usual single-GPU process never needs the switch)."""
+    return _NO_GUARD if dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -168,6 +185,25 @@ def set_grid_cache(enabled: bool, max_entries: int = 2) -> None:
     _GRID_CACHE_MAX = max(1, int(max_entries))
     if not enabled:
         _GRID_CACHE.clear()
+
+
+_SCRATCH = {}
+
+
+def _scratch(nbytes: int, dev):
+    """Workspace for one call.  Small ones (<= 4 MiB: the sliced brute-force scans of small batches) come from a grow-only
+    buffer per (device, stream): every user enqueues on that stream, in order, so the buffer can be handed out again at
+    once and a small call saves an allocator round trip (~2 us).  Big ones are allocated per call."""
+    if nbytes > (4 << 20):
+        return torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    key = (dev.index, _stream())
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if len(_SCRATCH) > 32:
+            _SCRATCH.clear()
+        buf = torch.empty((max(nbytes, 1 << 16),), dtype=torch.uint8, device=dev)
+        _SCRATCH[key] = buf
+    return buf
 
 
 def _sig(t):
@@ -214,7 +250,7 @@ def knn_points_idx(p1, p2, lengths1, lengths2, norm: int, K: int, version: int =
     P2 = p2.shape[1]
     if p2.shape[0] != N or p2.shape[2] != D or lengths1.shape != (N,) or lengths2.shape != (N,):
         raise RuntimeError("knn_points_idx: inconsistent shapes")
-    with torch.cuda.device(dev):
+    with _on(dev):
         idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
         dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
         ws_bytes = _lib.pointops_knn_workspace_bytes(N, P1, P2, D, K, version)
@@ -222,7 +258,7 @@ def knn_points_idx(p1, p2, lengths1, lengths2, norm: int, K: int, version: int =
         if _GRID_CACHE_ON and ws_bytes and _lib.pointops_knn_uses_grid(N, P1, P2, D, int(K), int(version)):
             ws, reuse = _grid_workspace(p1, p2, lengths1, lengths2, (N, P1, P2, D, int(K), int(version)), ws_bytes, dev)
         else:
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+            ws = _scratch(ws_bytes, dev) if ws_bytes else None
         _check(
             _lib.pointops_knn_points_idx_reuse(p1.data_ptr(), p2.data_ptr(), lengths1.data_ptr(),
                                                lengths2.data_ptr(), N, P1, P2, D, int(norm), int(K),
@@ -244,7 +280,7 @@ def knn_grid_fallback_counts(p1, p2, lengths1, lengths2, norm: int, K: int):
     P2 = p2.shape[1]
     if not knn_check_version(3, D, K):
         raise RuntimeError("grid family needs D <= 3 and K <= 128")
-    with torch.cuda.device(dev):
+    with _on(dev):
         idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
         dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
         ws_bytes = _lib.pointops_knn_workspace_bytes(N, P1, P2, D, K, 3)
@@ -271,7 +307,7 @@ def knn_grid_stats(p1, p2, lengths1, lengths2, norm: int, K: int):
     P2 = p2.shape[1]
     if not knn_check_version(3, D, K):
         raise RuntimeError("grid family needs D <= 3 and K <= 128")
-    with torch.cuda.device(dev):
+    with _on(dev):
         idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
         dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
         ws_bytes = _lib.pointops_knn_workspace_bytes(N, P1, P2, D, K, 3)
@@ -311,7 +347,7 @@ def knn_points_backward(p1, p2, lengths1, lengths2, idxs, norm: int, grad_dists,
     if (p2.shape[0] != N or p2.shape[2] != D or idxs.shape != (N, P1, K) or grad_dists.shape != (N, P1, K)
             or lengths1.shape != (N,) or lengths2.shape != (N,)):
         raise RuntimeError("knn_points_backward: inconsistent shapes")
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad_p1 = torch.empty((N, P1, D), dtype=torch.float32, device=dev)
         grad_p2 = torch.empty((N, P2, D), dtype=torch.float32, device=dev)
         if deterministic:
@@ -351,7 +387,7 @@ def ball_query(p1, p2, lengths1, lengths2, K: int, radius: float):
     K = int(K)
     if K < 0:
         raise RuntimeError("ball_query: K must be non-negative")
-    with torch.cuda.device(dev):
+    with _on(dev):
         idxs = torch.empty((N, P1, K), dtype=torch.int64, device=dev)
         dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
         ws_bytes = _lib.pointops_ball_query_workspace_bytes(N, P1, P2, D, int(K))
@@ -381,7 +417,7 @@ def sample_farthest_points(points, lengths, K, start_idxs):
         raise RuntimeError("sample_farthest_points: lengths, K and start_idxs must have shape (N,)")
     # host sync, as in the reference (sample_farthest_points.cu:132)
     max_K = int(K.max().item()) if N > 0 else 0
-    with torch.cuda.device(dev):
+    with _on(dev):
         idxs = torch.empty((N, max_K), dtype=torch.int64, device=dev)
         ws_bytes = _lib.pointops_fps_workspace_bytes(N, P, max_K)
         ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
@@ -403,7 +439,7 @@ def packed_to_padded(inputs_packed, first_idxs, max_size: int):
     _contig(first_idxs, "first_idxs")
     F, D = inputs_packed.shape
     B = first_idxs.shape[0]
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((B, max_size, D), dtype=torch.float32, device=dev)
         _check(
             _lib.pointops_packed_to_padded(inputs_packed.data_ptr(), first_idxs.data_ptr(), F, B,
@@ -421,7 +457,7 @@ def padded_to_packed(inputs_padded, first_idxs, num_inputs: int):
     _contig(inputs_padded, "inputs_padded")
     _contig(first_idxs, "first_idxs")
     B, M, D = inputs_padded.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((int(num_inputs), D), dtype=torch.float32, device=dev)
         _check(
             _lib.pointops_padded_to_packed(inputs_padded.data_ptr(), first_idxs.data_ptr(),
@@ -442,7 +478,7 @@ def sample_pdf(bins, weights, outputs, eps: float):
     batch, n_bins = weights.shape
     if bins.shape != (batch, n_bins + 1) or outputs.shape[0] != batch:
         raise RuntimeError("sample_pdf: inconsistent shapes")
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(
             _lib.pointops_sample_pdf(bins.data_ptr(), weights.data_ptr(), outputs.data_ptr(), batch, n_bins,
                                      outputs.shape[1], float(eps), _stream()),
@@ -459,7 +495,7 @@ def point_covariances(knn):
     dev = _require_gpu(knn)
     knn = knn.contiguous()
     N, P, K, D = knn.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         cov = torch.empty((N, P, D, D), dtype=torch.float32, device=dev)
         _check(_lib.pointops_point_covariances(knn.data_ptr(), N, P, K, D, cov.data_ptr(), _stream()),
                "point_covariances")
@@ -470,7 +506,7 @@ def point_covariances_backward(knn, grad_cov):
     dev = _require_gpu(knn, grad_cov)
     knn, grad_cov = knn.contiguous(), grad_cov.contiguous()
     N, P, K, D = knn.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad_knn = torch.empty_like(knn)
         _check(_lib.pointops_point_covariances_backward(knn.data_ptr(), grad_cov.data_ptr(), N, P, K, D,
                                                         grad_knn.data_ptr(), _stream()),
@@ -485,7 +521,7 @@ def gather_neighbors(x, idx, lengths=None):
     lengths = _i64c(lengths, "lengths") if lengths is not None else None
     N, M, U = x.shape
     _, L, K = idx.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((N, L, K, U), dtype=torch.float32, device=dev)
         _check(
             _lib.pointops_gather_neighbors(x.data_ptr(), idx.data_ptr(),
@@ -501,7 +537,7 @@ def gather_neighbors_backward(grad_out, idx, lengths, M: int, deterministic: boo
     grad_out, idx = _f32c(grad_out, "grad_out"), _i64c(idx, "idx")
     lengths = _i64c(lengths, "lengths") if lengths is not None else None
     N, L, K, U = grad_out.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad_x = torch.empty((N, M, U), dtype=torch.float32, device=dev)
         if deterministic:  # inverted neighbour table: every row of x sums its addends in table order
             ws_bytes = _lib.pointops_backward_det_workspace_bytes(N, L, K, M)
@@ -531,7 +567,7 @@ def chamfer_reduce(dists, lengths, weights, mean: bool):
     N, P = dists.shape
     if lengths.shape != (N,) or (weights is not None and weights.shape != (N,)):
         raise RuntimeError("chamfer_reduce: lengths / weights must have shape (N,)")
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((N,), dtype=torch.float32, device=dev)
         _check(
             _lib.pointops_chamfer_reduce(dists.data_ptr(), lengths.data_ptr(),
@@ -583,7 +619,7 @@ def chamfer_forward(dists, idx, x_lengths, y_lengths, weights, x_feats, y_feats,
     P2 = y_feats[0].shape[1] if F else 0
     _check_chamfer_shapes(N, P1, P2, idx, x_lengths, y_lengths, weights, x_feats, y_feats)
     C = (ctypes.c_int64 * max(F, 1))(*[int(t.shape[2]) for t in x_feats])
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((1 + F, N), dtype=torch.float32, device=dev)
         ws_bytes = _lib.pointops_chamfer_workspace_bytes(N, P1)
         ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
@@ -618,7 +654,7 @@ def chamfer_backward(x, y, idx, x_lengths, y_lengths, weights, grad_out, norm: i
         raise RuntimeError("chamfer_backward: inconsistent shapes")
     _check_chamfer_shapes(N, P1, P2, idx, x_lengths, y_lengths, weights, x_feats, y_feats)
     C = (ctypes.c_int64 * max(F, 1))(*[int(t.shape[2]) for t in x_feats])
-    with torch.cuda.device(dev):
+    with _on(dev):
         if into is None:
             grad_x = torch.empty_like(x)
             grad_y = torch.empty_like(y)

@@ -70,6 +70,11 @@ def knn_points(
         if norm not in (1, 2):
             raise ValueError("Support for 1 or 2 norm.")
         idx, dists = torch.ops.pointops_amd.knn_points_idx(p1, p2, lengths1, lengths2, norm, K, version)
+    elif not (torch.is_grad_enabled() and (p1.requires_grad or p2.requires_grad)):
+        # nothing to differentiate: no autograd node (6 us of a 57 us call at B=2, N=1024)
+        if not ((norm == 1) or (norm == 2)):
+            raise ValueError("Support for 1 or 2 norm.")
+        idx, dists = _C.knn_points_idx(p1, p2, lengths1, lengths2, norm, K, version)
     else:
         dists, idx = _knn_points.apply(p1, p2, lengths1, lengths2, K, version, norm, return_sorted)
     return _KNN(dists=dists, idx=idx, knn=knn_gather(p2, idx, lengths2) if return_nn else None)

@@ -1543,6 +1543,13 @@ def test_grid_reuse_between_calls(dev, oracle):
         fs, fq = fresh(tb, tb, tl2, tl2, 8), fresh(ta, tb, tl1, tl2, 8)
         assert torch.equal(s_i, fs[0]) and torch.equal(s_d, fs[1]) and torch.equal(r_i, fs[0]) and torch.equal(r_d, fs[1])
         assert torch.equal(q_i, fq[0]) and torch.equal(q_d, fq[1])
+        # long lists (the wave-sort search) reuse the grid the same way
+        w0 = _C.knn_points_idx(ta, tb, tl1, tl2, 2, 80, 3)
+        w1 = _C.knn_points_idx(ta, tb, tl1, tl2, 2, 80, 3)
+        w2 = _C.knn_points_idx(ta2, tb, tl1, tl2, 2, 80, 3)
+        fw, fw2 = fresh(ta, tb, tl1, tl2, 80), fresh(ta2, tb, tl1, tl2, 80)
+        assert torch.equal(w0[0], fw[0]) and torch.equal(w1[0], fw[0]) and torch.equal(w1[1], fw[1])
+        assert torch.equal(w2[0], fw2[0]) and torch.equal(w2[1], fw2[1])
         # the functional API goes through the same cache (chamfer against a fixed target: the target-side grid is kept)
         from pytorch3d_pointops_amd.functions.chamfer import chamfer_distance
 
