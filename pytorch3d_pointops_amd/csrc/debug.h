@@ -3,6 +3,8 @@
 // read at call time (one getenv per lookup, only on host launch paths).  Unset = every knob at its
 // default; no knob ever changes results, only which exact path computes them.
 //   knn_generic=1      knn_wide's plain generic kernel instead of its LDS-tiled forms
+//   knn_small=0|1      few queries: never / always the wave-per-query kernel (knn_small.hip; default: by shape)
+//   knn_small_q=1|2    that kernel: one query per wave / as many as the list size allows (default: by query count)
 //   grid_quad=0|1      force the quad pass of the grid KNN off / on (default: by the batch's query count)
 //   grid_long_box=0|1  K in (32, 64]: uncertified queries to the wave search / to the box search (default: by query count)
 //   grid_refine=0      no refined cells (over-full neighbourhoods still go to the box search, over whole cells)

@@ -288,12 +288,18 @@ static int choose_version(int version, int64_t N, int64_t P1, int64_t P2, int64_
   const bool grid_ok = pointops_knn_check_version(3, D, K) && P2 <= knn_grid_max_points();
   if (version == 3 && !grid_ok) version = -1;
   if (version >= 0 && version <= 3 && pointops_knn_check_version(version, D, K)) return version;
-  // auto: the grid only pays once the all-pairs scan is longer than the grid's floor of ~12 launches (0.08-0.1 ms);
-  // below that the sliced brute-force scan is faster.  The crossover in total pairs grows as K shrinks, because short
-  // lists make the scan cheap per pair (measured v2 against v3, N = 1..32 clouds of 4096..32768 points:
-  // profiles/r02_knn_crossover.txt; round 1's build passes put it at 1.5 * 2^29 / 2^28 / 2^27 for K <= 2 / 4 / 8).
-  const double pairs = (double)N * (double)P1 * (double)P2;
-  const double cross = K <= 2 ? (double)(1LL << 28) : K <= 4 ? (double)(1LL << 27) : (double)(1LL << 24);
+  // auto: the grid only pays once the all-pairs scan is longer than the grid's floor of ~12 launches (65 us at K=1,
+  // 80 at K=8, 120-130 at K=32).  Round 3's wave-per-query scan (knn_small.hip) moved the crossover up for lists of
+  // 8-16 slots (4096 x 4096, K=8: scan 25 us, grid 75; 4 x 4096 x 4096: 72 / 80; 2 x 8192 x 8192: 107 / 80) and made
+  // few-query shapes cheap enough to need a rule of their own: with fewer than 4096 queries the scan runs on a
+  // part-filled chip, so the pairs are counted as if there were 4096 (1024 x 65536: scan 80-200 us, grid 69-131;
+  // 512 x 262144: 297-492 / 74-139).  profiles/r03_knn_small_sweep.jsonl, r02_knn_crossover.txt.
+  const double pairs = (double)std::max<int64_t>(N * P1, 4096) * (double)P2;
+  const double cross = K <= 2 ? 1.5 * (double)(1LL << 27)    // K=1: 2 x 8192^2 scan 52 / grid 68; 16384^2 100 / 67
+                       : K <= 8 ? 1.5 * (double)(1LL << 26)  // K=8: 4 x 4096^2 69 / 80; 2 x 8192^2 99 / 79
+                       : K <= 16 ? (double)(1LL << 25)
+                       : K <= 32 ? 1.5 * (double)(1LL << 24)  // K=32: 4096^2 94 / 118; 4 x 4096^2 301 / 127
+                                 : (double)(1LL << 24);
   if (grid_ok && P2 >= 4096 && pairs >= cross) return 3;
   if (pointops_knn_check_version(2, D, K)) return 2;
   return 0;
@@ -304,6 +310,7 @@ size_t pointops_knn_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t D
   if (N <= 0 || P1 <= 0 || D < 1 || K < 1) return 0;
   const int v = choose_version(version, N, P1, P2, D, K);
   if (v == 0 && !knn_wide_supported(D, K)) return 0;
+  if ((v == 1 || v == 2) && knn_small_applies(N, P1, P2, D, K)) return 0;
   if (v != 3) return knn_split_workspace_bytes(N, P1, P2, K);
   return knn_grid_workspace_bytes(N, P1, P2, K);
 }
@@ -369,6 +376,8 @@ int pointops_knn_points_idx_reuse(const float* p1, const float* p2, const int64_
     else
       hipLaunchKernelGGL(knn_generic_kernel<2>, grid, dim3(kKnnBlock), 0, a.stream, p1, p2, lengths1,
                          lengths2, a.P1, a.P2, a.D, a.K, a.tiles, idxs, dists);
+  } else if (knn_small_applies(N, P1, P2, D, K)) {
+    launch_knn_small(a, norm);  // few queries: one wave per query (knn_small.hip)
   } else {
     const size_t need = knn_split_workspace_bytes(N, P1, P2, K);
     launch_knn_bruteforce(a, norm, workspace != nullptr && workspace_bytes >= need && need > 0 ? workspace : nullptr);

@@ -27,6 +27,10 @@ int knn_split_count(int64_t N, int64_t P1, int64_t P2, int64_t K);
 size_t knn_split_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K);
 void knn_merge_partials(const KnnArgs& a, int S, const void* workspace);
 
+// few queries (knn_small.hip): one wave per query, the cloud dealt over the lanes; D <= 8, K <= 32, no workspace
+bool knn_small_applies(int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K);
+void launch_knn_small(const KnnArgs& a, int norm);
+
 // brute-force scan for any D / long lists (knn_wide.hip): LDS-transposed queries, register or LDS lists
 bool knn_wide_supported(int64_t D, int64_t K);
 int launch_knn_wide(const KnnArgs& a, int norm, void* workspace);

@@ -156,6 +156,49 @@ def test_knn_wide_shapes(dev, oracle, monkeypatch, name):
     assert torch.equal(idx, idx2) and torch.equal(dists.view(torch.int32), dists2.view(torch.int32))
 
 
+_SMALL = {  # name: (N, P1, P2, D, K, norm, l1, l2)
+    "cfg1": (2, 1024, 1024, 3, 8, 2, [1024, 1024], [1024, 1024]),
+    "ragged_k_gt_len2": (3, 130, 700, 3, 16, 2, [130, 0, 77], [700, 5, 0]),
+    "k1_l1": (2, 200, 333, 3, 1, 1, [200, 199], [333, 1]),
+    "k32_d8": (2, 65, 515, 8, 32, 2, [65, 64], [515, 40]),
+    "k24_d5": (1, 100, 1000, 5, 24, 1, [100], [999]),
+    "k2_d1": (2, 300, 257, 1, 2, 2, [300, 1], [257, 256]),
+    "k4_d2_lattice": (2, 256, 900, 2, 4, 2, [256, 100], [900, 899]),
+    "k16_lattice": (2, 128, 2000, 3, 16, 2, [128, 128], [2000, 64]),
+    "few_queries_long_cloud": (1, 7, 20000, 3, 8, 2, [6], [20000]),
+    "many_queries_per_wave": (1, 40000, 100, 3, 4, 2, [39999], [100]),  # 3 queries per wave
+    "identical_points": (1, 70, 300, 3, 8, 2, [70], [300]),
+}
+
+
+@pytest.mark.parametrize("per_wave", ["one", "shared"])
+@pytest.mark.parametrize("name", sorted(_SMALL))
+def test_knn_small_batches(dev, oracle, monkeypatch, name, per_wave):
+    """Few queries (knn_small.hip: one wave per query, the cloud dealt over the lanes, answers pulled out of the 64
+    list heads by wave-wide minima), forced on: bit-exact against the oracle -- ragged lengths, K > len2, ties
+    (lattices, identical points: the smaller index wins), D = 1..8, both norms -- and identical to the sliced
+    lane-per-query scan it replaces at these sizes.  "shared": up to four queries per wave share each loaded
+    candidate (ragged query counts leave partial groups); the long cloud exercises the wave-uniform gates."""
+    from pytorch3d_pointops_amd import _C
+
+    N, P1, P2, D, K, norm, l1, l2 = _SMALL[name]
+    p1 = cases.cloud(1900 + D, (N, P1, D))
+    p2 = cases.cloud(1901 + D + K, (N, P2, D))
+    if "lattice" in name:
+        p1, p2 = cases.lattice(1902, N, P1, D, levels=5), cases.lattice(1903, N, P2, D, levels=5)
+    if name == "identical_points":
+        p2[:] = np.float32(0.25)
+    l1, l2 = np.array(l1), np.array(l2)
+    monkeypatch.setenv("POINTOPS_DEBUG", "knn_small=1,knn_small_q=" + ("1" if per_wave == "one" else "2"))
+    idx, dists = _C.knn_points_idx(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm, K, 2)
+    oi, od = oracle.knn_points_idx(p1, p2, l1, l2, norm, K)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(bits(dists.cpu().numpy()), bits(od))
+    monkeypatch.setenv("POINTOPS_DEBUG", "knn_small=0")
+    idx2, dists2 = _C.knn_points_idx(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), norm, K, 2)
+    assert torch.equal(idx, idx2) and torch.equal(dists.view(torch.int32), dists2.view(torch.int32))
+
+
 @pytest.mark.parametrize("name", sorted(_grid_adversarial_cases()))
 def test_knn_grid_adversarial(dev, oracle, name):
     """Grid search vs the CPU oracle on distributions that stress the bound / fallback logic,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one op of the config table a few times (for rocprofv3): python tools/run_op.py ball_query [iters]
-   ops: ball_query (cfg3: B=16 N=131072 r=0.2 K=32, self query) | fps (cfg3) | knn (cfg2)"""
+   ops: knn_cfg1 | ball_query (cfg3: B=16 N=131072 r=0.2 K=32, self query) | fps (cfg3) | knn (cfg2)"""
 import os
 import sys
 import time
@@ -39,6 +39,10 @@ elif op in ("knn_reuse", "knn_reuse_new_queries"):  # cfg2 with the opt-in grid 
     def fn():
         qs.reverse()
         return _C.knn_points_idx(qs[0], p2, L, L, 2, 16, -1)
+elif op == "knn_cfg1":  # BASELINE.json configs[0]: B=2, N=M=1024, K=8, self query
+    a = torch.from_numpy(synth.uniform_f32(1, (2, 1024, 3))).to(dev)
+    L = torch.full((2,), 1024, dtype=torch.int64, device=dev)
+    fn = lambda: _C.knn_points_idx(a, a, L, L, 2, 8, -1)  # noqa: E731
 elif op == "knn_k100":
     B, P = 1, 300000
     p1 = torch.from_numpy(synth.uniform_f32(3811, (B, P, 3))).to(dev)
