@@ -482,6 +482,10 @@ extern "C" int pointops_ball_query(const float* p1, const float* p2, const int64
     const int rc = ball_grid_run(a, radius, workspace, &flag, &qcount, &qlist);
     if (rc != POINTOPS_OK) return rc;
   }
+  if (flag == nullptr && ball_small_applies(N, P1, P2, D, K)) {  // few queries: one wave per query (ball_small.hip)
+    launch_ball_small(p1, p2, lengths1, lengths2, N, P1, P2, D, K, radius2, idxs, dists, stream);
+    return check_launch("ball_query(small)");
+  }
   // listed clouds (every cloud once the lists exist) with hits staged in LDS: K a multiple of 4 up to 64
   const bool staged = flag != nullptr && D <= 4 && K <= 64 && K % 4 == 0 && debug_knob("ball_stage", 1) != 0;
   if (staged) {

@@ -10,6 +10,7 @@
 //   grid_refine=0      no refined cells (over-full neighbourhoods still go to the box search, over whole cells)
 //   grid_same=0        do not reuse the point sort as the query order when p1 is p2
 //   grid_c_scale=F     multiply the grid KNN's points-per-cell target (sweeps)
+//   ball_small=0|1     ball query, few queries: never / always the wave-per-query kernel (ball_small.hip; default: by shape)
 //   ball_grid=0|1      ball query: never / whenever possible through the grid (default: by shape)
 //   ball_factor=F      ball query: grid-or-scan crossover constant
 //   ball_order=0       ball query: scan-mode clouds keep their queries in storage order (no coarse-cell order)

@@ -47,6 +47,12 @@ size_t knn_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t K);
 // 2 = and the query side (p1, lengths1) too
 int knn_grid_run(const KnnArgs& a, int norm, void* workspace, int reuse = 0);
 
+// ball query for few queries (ball_small.hip): one wave per query, any D, any K, no workspace
+bool ball_small_applies(int64_t N, int64_t P1, int64_t P2, int64_t D, int64_t K);
+void launch_ball_small(const float* p1, const float* p2, const int64_t* lengths1, const int64_t* lengths2, int64_t N,
+                       int64_t P1, int64_t P2, int64_t D, int64_t K, float radius2, int64_t* idxs, float* dists,
+                       hipStream_t stream);
+
 // ball query through the same grid (knn_grid.hip); see ball_query.hip for the operator
 size_t ball_grid_workspace_bytes(int64_t N, int64_t P1, int64_t P2);
 int ball_grid_run(const KnnArgs& a, float radius, void* workspace, const int** flag, const int** qcount,

@@ -393,10 +393,14 @@ def test_knn_gather_and_masked_gather(dev):
 
 
 # ------------------------------------------------------------------ ball query
+@pytest.mark.parametrize("kernel", ["lane_per_query", "wave_per_query"])
 @pytest.mark.parametrize("name", sorted(cases.ball_query_cases()))
-def test_ball_query(dev, oracle, name):
+def test_ball_query(dev, oracle, monkeypatch, name, kernel):
+    """Reference goldens and the oracle, through the lane-per-query scan (ball_query.hip) and through the
+    wave-per-query kernel that small batches take (ball_small.hip)."""
     from pytorch3d_pointops_amd.functions import ball_query
 
+    monkeypatch.setenv("POINTOPS_DEBUG", "ball_small=" + ("1" if kernel == "wave_per_query" else "0"))
     g = load_golden("ball_query")
     c = cases.ball_query_cases()[name]
     p1 = G(c["p1"], dev).requires_grad_(True)
@@ -416,14 +420,17 @@ def test_ball_query(dev, oracle, name):
     assert close(p2.grad.cpu().numpy(), g[name + "/grad_p2"])
 
 
-@pytest.mark.parametrize("radius,K", [(0.05, 16), (0.3, 8), (0.12, 64)])
-def test_ball_query_larger_clouds(dev, oracle, radius, K):
+@pytest.mark.parametrize("kernel", ["lane_per_query", "wave_per_query"])
+@pytest.mark.parametrize("radius,K,D", [(0.05, 16, 3), (0.3, 8, 3), (0.12, 64, 3), (0.3, 500, 3), (0.2, 20, 2), (0.6, 33, 6)])
+def test_ball_query_larger_clouds(dev, oracle, monkeypatch, radius, K, D, kernel):
     """Larger clouds: sparse balls (queries that never fill scan everything), dense balls (early
-    exit), K = 64, ragged lengths."""
+    exit), K = 64 and the reference's default K = 500, ragged lengths, D = 2 / 3 and the run-time-D path (6);
+    both kernels."""
     from pytorch3d_pointops_amd import _C
 
-    p1 = cases.cloud(1501, (2, 3000, 3))
-    p2 = cases.cloud(1502, (2, 20000, 3))
+    monkeypatch.setenv("POINTOPS_DEBUG", "ball_small=" + ("1" if kernel == "wave_per_query" else "0"))
+    p1 = cases.cloud(1501, (2, 3000, D))
+    p2 = cases.cloud(1502, (2, 20000, D))
     l1 = np.array([3000, 1234])
     l2 = np.array([20000, 6000])
     idx, d = _C.ball_query(G(p1, dev), G(p2, dev), G(l1, dev), G(l2, dev), K, radius)
