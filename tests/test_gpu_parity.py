@@ -318,17 +318,18 @@ def test_knn_backward_modes(dev, oracle, monkeypatch, mode, split, D, norm, K):
     assert close(g1b.cpu().numpy(), o1b) and close(g2b.cpu().numpy(), o2b)
 
 
+@pytest.mark.parametrize("K", [6, 8])
 @pytest.mark.parametrize("U", [1, 2, 3, 4, 7, 64])
-def test_knn_gather_widths(dev, U):
-    """knn_gather forward for every kernel variant (row kernels U <= 4, element kernel above) against the
-    numpy restatement of functions/knn.py:200-250, with -1 rows and k >= lengths masking."""
+def test_knn_gather_widths(dev, U, K):
+    """knn_gather forward for every kernel variant (row kernels U <= 4, element kernel above) against the numpy restatement of functions/knn.py:200-250, with -1 rows
+    and k >= lengths masking."""
     from oracle import oracle as O
     from pytorch3d_pointops_amd import _C, synth
 
-    N, M, L, K = 3, 500, 333, 6
+    N, M, L = 3, 500, 333
     x = cases.cloud(1900 + U, (N, M, U))
     idx = synth.randint(1901, 0, M - 1, (N, L, K))
-    lengths = np.array([6, 2, 0])
+    lengths = np.array([K, 2, 0])
     out = _C.gather_neighbors(G(x, dev), G(idx, dev), G(lengths, dev))
     assert np.array_equal(out.cpu().numpy(), O.knn_gather(x, idx, lengths))
     idx2 = idx.copy()
