@@ -204,14 +204,29 @@ __device__ __forceinline__ float fps_min(float a, float b) {  // IEEE minNum: a 
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-__device__ __forceinline__ double fps_wave_max(double k) {
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) {
-    const int hi = __shfl_xor(__double2hiint(k), off, kWave);
-    const int lo = __shfl_xor(__double2loint(k), off, kWave);
-    k = fps_max(k, __hiloint2double(hi, lo));
-  }
+// k = max(k, k of the lane that DPP control CTRL names); lanes outside the rows of ROWS keep k.  Two v_mov_b32_dpp and
+// one v_max_f64: ~25 cycles a step, where the ds_bpermute pair of __shfl_xor costs ~120 (a trip through the LDS pipe)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double fps_dpp_max(double k) {
+  const int hi = __double2hiint(k), lo = __double2loint(k);
+  const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWS, 0xf, false);
+  const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWS, 0xf, false);
+  return fps_max(k, __hiloint2double(ohi, olo));
+}
+// maximum over each row of 16 lanes, in every lane of the row
+__device__ __forceinline__ double fps_row_max(double k) {
+  k = fps_dpp_max<0xB1, 0xf>(k);   // quad_perm [1,0,3,2]
+  k = fps_dpp_max<0x4E, 0xf>(k);   // quad_perm [2,3,0,1]
+  k = fps_dpp_max<0x124, 0xf>(k);  // row_ror 4
+  k = fps_dpp_max<0x128, 0xf>(k);  // row_ror 8
   return k;
+}
+// maximum over the wave, wave-uniform (row maxima carried up the rows into lane 63, read back through SGPRs)
+__device__ __forceinline__ double fps_wave_max(double k) {
+  k = fps_row_max(k);
+  k = fps_dpp_max<0x142, 0xa>(k);  // row_bcast15 into rows 1, 3
+  k = fps_dpp_max<0x143, 0xc>(k);  // row_bcast31 into rows 2, 3
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(k), 63), __builtin_amdgcn_readlane(__double2loint(k), 63));
 }
 
 __device__ __forceinline__ unsigned xcc_id() {
@@ -348,13 +363,9 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
       if (lane == 0) s_key[wave] = best;
       __syncthreads();
       if (wave == 0) {
+        static_assert(kFpsWaves == 16, "one DPP row holds the waves' keys");
         double v = lane < kFpsWaves ? s_key[lane] : __hiloint2double(__float_as_int(-2.0f), 0);
-#pragma unroll
-        for (int off = kFpsWaves / 2; off > 0; off >>= 1) {
-          const int hi = __shfl_xor(__double2hiint(v), off, kWave);
-          const int lo = __shfl_xor(__double2loint(v), off, kWave);
-          v = fps_max(v, __hiloint2double(hi, lo));
-        }
+        v = fps_row_max(v);  // (lanes 0..15: the workgroup's maximum)
         // this member's key: distance bits << 32 | ~index (never 0); 1 when it holds no valid point
         const unsigned long long key = __double2hiint(v) >= 0 ? (unsigned long long)__double_as_longlong(v) : 1ull;
         int win = (int)(0xffffffffu - (unsigned)(key & 0xffffffffull));  // valid in lane 0 (G == 1: the result)
