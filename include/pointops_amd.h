@@ -251,6 +251,32 @@ int pointops_chamfer_backward_accumulate(const float* x, const float* y, const i
                                          float* const* grad_x_feats, float* const* grad_y_feats, void* stream);
 
 /*
+ * BOTH directions of an unweighted chamfer distance with point_reduction in {"sum","mean"} behind one entry (no
+ * reference counterpart; the composition of `chamfer_distance`, reference: functions/chamfer.py:188-312, for
+ * weights=None): the K=1 searches x -> y and y -> x (pointops_knn_points_idx), pointops_chamfer_forward on each, the
+ * sum of the two directions and the batch reduction.
+ *   batch_reduction: 0 = None -> each of the 1+F outputs is (N,);  1 = "mean", 2 = "sum" -> each is one float
+ *   outs: HOST array of 1+F device pointers (the point term, then one per feature pair)
+ *   idx_xy (N,P1), idx_yx (N,P2): the neighbour indices, outputs, needed by the backward.
+ * The backward takes 1+F gradient pointers (HOST array; a null entry is a zero gradient; each points to one float
+ * after a batch reduction, to N floats without one) and writes grad_x, grad_y, grad_x_feats, grad_y_feats
+ * (every element written: no pre-zeroing needed); workspace: (1+F)*N floats.
+ */
+size_t pointops_chamfer_pair_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t D, int F);
+int pointops_chamfer_pair_forward(const float* x, const float* y, const int64_t* x_lengths,
+                                  const int64_t* y_lengths, int64_t N, int64_t P1, int64_t P2, int64_t D, int norm,
+                                  int F, const float* const* x_feats, const float* const* y_feats, const int64_t* C,
+                                  int abs_cosine, int mean, int batch_reduction, int64_t* idx_xy, int64_t* idx_yx,
+                                  float* const* outs, void* workspace, size_t workspace_bytes, void* stream);
+int pointops_chamfer_pair_backward(const float* x, const float* y, const int64_t* idx_xy, const int64_t* idx_yx,
+                                   const int64_t* x_lengths, const int64_t* y_lengths, const float* const* grads,
+                                   int64_t N, int64_t P1, int64_t P2, int64_t D, int norm, int F,
+                                   const float* const* x_feats, const float* const* y_feats, const int64_t* C,
+                                   int abs_cosine, int mean, int batch_reduction, float* grad_x, float* grad_y,
+                                   float* const* grad_x_feats, float* const* grad_y_feats, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
+/*
  * Inverse-CDF sampling -- replaces `_C.sample_pdf` (reference: csrc/sample_pdf/sample_pdf.h:58-78,
  * CPU semantics sample_pdf_cpu.cpp:19-99, the USE_BINARY_SEARCH build).
  *   bins (batch, n_bins+1), weights (batch, n_bins), outputs (batch, n_samples) holding the quantiles

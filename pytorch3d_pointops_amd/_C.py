@@ -66,6 +66,11 @@ _SIGNATURES = {
                                          _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "pointops_chamfer_backward_accumulate": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int,
                                                     _int, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "pointops_chamfer_pair_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int]),
+    "pointops_chamfer_pair_forward": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _vp, _vp,
+                                             _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pointops_chamfer_pair_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _int,
+                                              _vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 
@@ -675,5 +680,90 @@ def chamfer_backward(x, y, idx, x_lengths, y_lengths, weights, grad_out, norm: i
                   F, _ptr_array(x_feats), _ptr_array(y_feats), C, int(bool(abs_cosine)), int(bool(mean)),
                   grad_x.data_ptr(), grad_y.data_ptr(), _ptr_array(gxf), _ptr_array(gyf), _stream()),
             "chamfer_backward",
+        )
+    return grad_x, grad_y, gxf, gyf
+
+
+_BATCH_REDUCTION = {None: 0, "mean": 1, "sum": 2}
+
+
+def grid_cache_enabled() -> bool:
+    return _GRID_CACHE_ON
+
+
+def chamfer_pair_forward(x, y, x_lengths, y_lengths, norm: int, x_feats, y_feats, abs_cosine: bool, mean: bool,
+                         batch_reduction):
+    """Both directions of an unweighted chamfer distance in ONE native call (pointops_chamfer_pair_forward):
+    returns (outs, idx_xy (N,P1), idx_yx (N,P2)); outs = 1+F tensors, () after a batch reduction, (N,) without one."""
+    dev = _require_gpu(x, y, x_lengths, y_lengths, *x_feats, *y_feats)
+    x, y = _f32c(x, "x"), _f32c(y, "y")
+    x_lengths, y_lengths = _i64c(x_lengths, "x_lengths"), _i64c(y_lengths, "y_lengths")
+    x_feats = [_f32c(t, "x_feats") for t in x_feats]
+    y_feats = [_f32c(t, "y_feats") for t in y_feats]
+    if norm not in (1, 2):
+        raise ValueError("Support for 1 or 2 norm.")
+    N, P1, D = x.shape
+    P2 = y.shape[1]
+    F = len(x_feats)
+    if y.shape[0] != N or y.shape[2] != D:
+        raise RuntimeError("chamfer_pair_forward: inconsistent shapes")
+    for a, b in zip(x_feats, y_feats):  # (the index shapes are ours; the feature checks are the single direction's)
+        if a.dim() != 3 or b.dim() != 3 or a.shape[:2] != (N, P1) or b.shape[:2] != (N, P2) \
+                or a.shape[2] != b.shape[2] or not 1 <= a.shape[2] <= CHAMFER_MAX_CHANNELS:
+            raise RuntimeError("chamfer: features must be (N, P1, C) / (N, P2, C) with 1 <= C <= "
+                               f"{CHAMFER_MAX_CHANNELS}")
+    if len(x_feats) != len(y_feats) or F > CHAMFER_MAX_FEATURES or x_lengths.shape != (N,) or y_lengths.shape != (N,):
+        raise RuntimeError(f"chamfer: at most {CHAMFER_MAX_FEATURES} feature pairs, lengths of shape (N,)")
+    C = (ctypes.c_int64 * max(F, 1))(*[int(t.shape[2]) for t in x_feats])
+    red = _BATCH_REDUCTION[batch_reduction]
+    with _on(dev):
+        idx_xy = torch.empty((N, P1), dtype=torch.int64, device=dev)
+        idx_yx = torch.empty((N, P2), dtype=torch.int64, device=dev)
+        outs = [torch.empty(() if red else (N,), dtype=torch.float32, device=dev) for _ in range(1 + F)]
+        ws_bytes = _lib.pointops_chamfer_pair_workspace_bytes(N, P1, P2, D, F)
+        ws = _scratch(ws_bytes, dev) if ws_bytes else None
+        _check(
+            _lib.pointops_chamfer_pair_forward(x.data_ptr(), y.data_ptr(), x_lengths.data_ptr(), y_lengths.data_ptr(), N,
+                                               P1, P2, D, int(norm), F, _ptr_array(x_feats), _ptr_array(y_feats), C,
+                                               int(bool(abs_cosine)), int(bool(mean)), red, idx_xy.data_ptr(),
+                                               idx_yx.data_ptr(), _ptr_array(outs),
+                                               ws.data_ptr() if ws is not None else None, ws_bytes, _stream()),
+            "chamfer_pair_forward",
+        )
+    return outs, idx_xy, idx_yx
+
+
+def chamfer_pair_backward(x, y, idx_xy, idx_yx, x_lengths, y_lengths, grads, norm: int, x_feats, y_feats,
+                          abs_cosine: bool, mean: bool, batch_reduction):
+    """Gradients of chamfer_pair_forward's 1+F outputs (`grads`: one tensor or None per output) in ONE native call:
+    returns (grad_x, grad_y, [grad_x_feat], [grad_y_feat])."""
+    live = [g for g in grads if g is not None]
+    dev = _require_gpu(x, y, idx_xy, idx_yx, x_lengths, y_lengths, *live, *x_feats, *y_feats)
+    N, P1, D = x.shape
+    P2 = y.shape[1]
+    F = len(x_feats)
+    red = _BATCH_REDUCTION[batch_reduction]
+    want = () if red else (N,)
+    if len(grads) != 1 + F or any(g.shape != want for g in live):
+        raise RuntimeError("chamfer_pair_backward: one gradient per output, () after a batch reduction, (N,) without")
+    live = [_f32c(g, "grad") for g in live]
+    it = iter(live)
+    garr = (ctypes.c_void_p * (1 + F))(*[None if g is None else next(it).data_ptr() for g in grads])
+    C = (ctypes.c_int64 * max(F, 1))(*[int(t.shape[2]) for t in x_feats])
+    with _on(dev):
+        grad_x = torch.empty_like(x)
+        grad_y = torch.empty_like(y)
+        gxf = [torch.empty_like(t) for t in x_feats]
+        gyf = [torch.empty_like(t) for t in y_feats]
+        ws_bytes = 4 * (1 + F) * N
+        ws = _scratch(ws_bytes, dev)
+        _check(
+            _lib.pointops_chamfer_pair_backward(x.data_ptr(), y.data_ptr(), idx_xy.data_ptr(), idx_yx.data_ptr(),
+                                                x_lengths.data_ptr(), y_lengths.data_ptr(), garr, N, P1, P2, D,
+                                                int(norm), F, _ptr_array(x_feats), _ptr_array(y_feats), C,
+                                                int(bool(abs_cosine)), int(bool(mean)), red, grad_x.data_ptr(),
+                                                grad_y.data_ptr(), _ptr_array(gxf), _ptr_array(gyf), ws.data_ptr(),
+                                                ws_bytes, _stream()),
+            "chamfer_pair_backward",
         )
     return grad_x, grad_y, gxf, gyf

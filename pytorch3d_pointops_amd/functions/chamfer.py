@@ -161,6 +161,13 @@ class _chamfer_pair(Function):
         y_feats = [f.contiguous() for f in feats[F_:]]
         x, y = x.contiguous(), y.contiguous()
         N = x.shape[0]
+        ctx.cfg = (int(norm), bool(mean), bool(abs_cosine), batch_reduction, F_)
+        ctx.native = not _C.grid_cache_enabled()
+        if ctx.native:  # one native call (the opt-in grid cache keeps the composed calls: its bookkeeping is Python's)
+            outs, idx_xy, idx_yx = _C.chamfer_pair_forward(x, y, x_lengths, y_lengths, norm, x_feats, y_feats,
+                                                           abs_cosine, mean, batch_reduction)
+            ctx.save_for_backward(x, y, idx_xy, idx_yx, x_lengths, y_lengths, *x_feats, *y_feats)
+            return tuple(outs)
 
         def direction(a, b, a_len, b_len, a_feats, b_feats):
             idx, dists = _C.knn_points_idx(a, b, a_len, b_len, norm, 1, -1)
@@ -176,7 +183,6 @@ class _chamfer_pair(Function):
             if batch_reduction == "mean":
                 rows /= max(N, 1)
         ctx.save_for_backward(x, y, idx_xy, idx_yx, x_lengths, y_lengths, *x_feats, *y_feats)
-        ctx.cfg = (int(norm), bool(mean), bool(abs_cosine), batch_reduction, F_)
         return tuple(r.clone() for r in rows.unbind(0))
 
     @staticmethod
@@ -187,6 +193,11 @@ class _chamfer_pair(Function):
         x_feats = list(ctx.saved_tensors[6:6 + F_])
         y_feats = list(ctx.saved_tensors[6 + F_:6 + 2 * F_])
         N = x.shape[0]
+        alert_not_deterministic("chamfer_distance backward")  # grad of the TARGET cloud: fp32 atomics
+        if ctx.native:
+            gx, gy, gxf, gyf = _C.chamfer_pair_backward(x, y, idx_xy, idx_yx, xl, yl, grads, norm, x_feats, y_feats,
+                                                        abs_cosine, mean, batch_reduction)
+            return (gx, gy, None, None, None, None, None, None, *gxf, *gyf)
         like = next(g for g in grads if g is not None)
         g = torch.stack([torch.zeros_like(like) if gi is None else gi for gi in grads]).float()
         if batch_reduction is not None:  # (1+F,) -> the same value for every cloud
@@ -194,7 +205,6 @@ class _chamfer_pair(Function):
                 g = g / max(N, 1)
             g = g[:, None].expand(1 + F_, N)
         g = g.contiguous()
-        alert_not_deterministic("chamfer_distance backward")  # grad of the TARGET cloud: fp32 atomics
         gx, gy, gxf, gyf = _C.chamfer_backward(x, y, idx_xy, xl, yl, None, g, norm, x_feats, y_feats, abs_cosine,
                                                mean)
         # the reverse direction ADDS into the same buffers (its dense terms into gy, its atomics into gx): no second

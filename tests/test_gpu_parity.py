@@ -875,6 +875,51 @@ def test_cfg4_chamfer_fused_vs_composed(dev, monkeypatch):
         assert close(a[2][k].cpu().numpy(), b[2][k].cpu().numpy(), tol=2e-5), k
 
 
+@pytest.mark.parametrize("batch_reduction", [None, "mean", "sum"])
+@pytest.mark.parametrize("with_normals", [False, True])
+def test_chamfer_pair_native_vs_composed(dev, monkeypatch, batch_reduction, with_normals):
+    """The one-call bidirectional chamfer (pointops_chamfer_pair_forward / _backward: both searches, both fused
+    reductions, the sum of the directions, the batch reduction and its backward in native code) against the composed
+    path that the reference goldens pin (knn_points / knn_gather / torch ops), ragged lengths, a missing gradient
+    (only the point loss is back-propagated in one of the runs): values and all gradients."""
+    import pytorch3d_pointops_amd.functions.chamfer as ch
+
+    N, P1, P2 = 5, 700, 900
+    l1, l2 = np.array([700, 1, 350, 699, 20]), np.array([900, 450, 1, 33, 899])
+    base = dict(x=cases.cloud(2101, (N, P1, 3)), y=cases.cloud(2102, (N, P2, 3)))
+    if with_normals:
+        base.update(xn=cases.cloud(2103, (N, P1, 3)) - np.float32(0.5), yn=cases.cloud(2104, (N, P2, 3)) - np.float32(0.5))
+
+    def run(point_reduction, only_points):
+        t = {k: G(v, dev).requires_grad_(True) for k, v in base.items()}
+        kw = dict(x_features={"normals": t["xn"]}, y_features={"normals": t["yn"]}, feature_names=["normals"]) \
+            if with_normals else {}
+        loss, lf = ch.chamfer_distance(t["x"], t["y"], x_lengths=G(l1, dev), y_lengths=G(l2, dev),
+                                       batch_reduction=batch_reduction, point_reduction=point_reduction, **kw)
+        total = loss.sum() * 1.5
+        if with_normals and not only_points:
+            total = total + lf["normals"].sum() * 0.25
+        total.backward()
+        return [loss.detach()] + ([lf["normals"].detach()] if with_normals else []), {k: v.grad for k, v in t.items()}
+
+    for point_reduction in ("mean", "sum"):
+        for only_points in (False, True):
+            a = run(point_reduction, only_points)
+            with monkeypatch.context() as m:
+                m.setattr(ch, "_fused_direction_ok", lambda *args, **kw: False)
+                b = run(point_reduction, only_points)
+            for u, v in zip(a[0], b[0]):
+                assert u.shape == v.shape and close(u.cpu().numpy(), v.cpu().numpy())
+            for k in base:
+                if a[1][k] is None or b[1][k] is None:  # (features without a back-propagated loss)
+                    assert only_points and k in ("xn", "yn")
+                    ga = a[1][k].cpu().numpy() if a[1][k] is not None else 0.0
+                    gb = b[1][k].cpu().numpy() if b[1][k] is not None else 0.0
+                    assert np.all(ga == 0.0) and np.all(gb == 0.0)
+                    continue
+                assert close(a[1][k].cpu().numpy(), b[1][k].cpu().numpy(), tol=2e-5), (k, point_reduction, only_points)
+
+
 # ------------------------------------------------------------------ sample_pdf (SURVEY.md section 8 f4)
 @pytest.mark.parametrize("name", sorted(cases.sample_pdf_cases()))
 def test_sample_pdf(dev, oracle, name):
