@@ -466,11 +466,24 @@ static int fps_num_cus() {
   return cus[dev];
 }
 
-// cluster geometry of the register-resident kernel: points per lane and workgroups per cloud
-static void fps_plan(int64_t P, int* ppt, int* G) {
+// cluster geometry of the register-resident kernel: points per lane and workgroups per cloud.
+// Round 3: a cloud that needs an exchange anyway (more than 8192 points) takes FOUR points per lane -- twice the
+// workgroups, half the arithmetic per iteration and workgroup -- while the batch still gets a CU per workgroup and a cloud
+// still fits one XCD: 1 x 131072 -> 1024: 1.50 -> 1.35 ms, 4 x 32768 -> 512: 0.73 -> 0.64, 32 x 16384 -> 256: 0.38 -> 0.34.
+// Not beyond that: two workgroups per CU (the <3, 4> kernel held to 64 VGPRs) do not overlap each other's latency
+// (16 x 131072: 1.51 -> 1.73 ms), and a cloud that fits one workgroup is fastest without an exchange (64 x 8192 -> 256:
+// 0.26 against 0.33 ms).  tools/fps_plan_sweep.py, profiles/r03_fps_plan_sweep.txt.
+// D <= 0: the plan with the most workgroups per cloud any D could take (workspace sizing).
+static void fps_plan(int64_t N, int64_t P, int64_t D, int* ppt, int* G) {
   const int cus = fps_num_cus();
   int p = P <= 8 * (int64_t)kFpsBlock * cus ? 8 : 16;
   if (P <= 4 * (int64_t)kFpsBlock) p = 4;
+  if (p == 8 && (D == 3 || D <= 0) && debug_knob("fps_small_ppt", 1) != 0) {
+    const int64_t g4 = ceil_div(P, (int64_t)4 * kFpsBlock);
+    if (P > 8 * (int64_t)kFpsBlock && N * g4 <= (int64_t)cus && g4 <= (int64_t)cus / 8) p = 4;
+  }
+  const long forced = debug_knob("fps_ppt", 0);  // experiments: 4 | 8 | 16
+  if (forced == 4 || forced == 8 || forced == 16) p = (int)forced;
   *ppt = p;
   *G = (int)ceil_div(P > 0 ? P : 1, (int64_t)p * kFpsBlock);
 }
@@ -495,7 +508,7 @@ extern "C" size_t pointops_fps_workspace_bytes(int64_t N, int64_t P, int64_t max
   // v1 running min-distance array (N*P floats) + v2 exchange rows: one u64 slot per
   // (cloud, iteration, cluster member) + one timeout word per cloud
   int ppt, G;
-  fps_plan(P, &ppt, &G);
+  fps_plan(N, P, 0, &ppt, &G);
   const size_t md = sizeof(float) * (size_t)(N * P);
   const size_t ex = fps_slot_bytes(N, max_K, G) + sizeof(unsigned) * (size_t)N + 64;
   return ((md + 255) & ~(size_t)255) + ex;
@@ -517,7 +530,7 @@ extern "C" int pointops_sample_farthest_points(const float* points, const int64_
   float* min_dist_ws = (float*)workspace;
   char* ex = (char*)workspace + ((sizeof(float) * (size_t)(N * P) + 255) & ~(size_t)255);
   int ppt, G;
-  fps_plan(P, &ppt, &G);
+  fps_plan(N, P, D, &ppt, &G);
   const size_t slot_bytes = fps_slot_bytes(N, max_K, G);
   unsigned long long* slots = (unsigned long long*)ex;
   unsigned* timeout_flags = (unsigned*)(ex + slot_bytes);
