@@ -50,6 +50,8 @@ def ball_query(
     p1, p2, lengths1, lengths2 = point_pair(p1, p2, lengths1, lengths2)
     if torch.compiler.is_compiling():  # traced graphs see the registered op (pytorch3d_pointops_amd/ops.py)
         idx, dists = torch.ops.pointops_amd.ball_query(p1, p2, lengths1, lengths2, K, radius)
+    elif not (torch.is_grad_enabled() and (p1.requires_grad or p2.requires_grad)):
+        idx, dists = _C.ball_query(p1, p2, lengths1, lengths2, K, radius)  # nothing to differentiate: no autograd node
     else:
         dists, idx = _BallQueryFn.apply(p1, p2, lengths1, lengths2, K, radius)
     return _KNN(dists=dists, idx=idx, knn=masked_gather(p2, idx) if return_nn else None)

@@ -120,6 +120,8 @@ def knn_gather(x: torch.Tensor, idx: torch.Tensor, lengths: Union[torch.Tensor, 
         return _knn_gather_torch(x, idx, lengths)
     if torch.compiler.is_compiling():
         return torch.ops.pointops_amd.gather_neighbors(x, idx, lengths)
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return _C.gather_neighbors(x, idx, lengths)  # nothing to differentiate: no autograd node
     return _gather_neighbors.apply(x, idx, lengths)
 
 

@@ -28,6 +28,8 @@ def masked_gather(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     table = idx if idx.ndim == 3 else idx[:, :, None]
     if torch.compiler.is_compiling():
         out = torch.ops.pointops_amd.gather_neighbors(points, table.contiguous(), None)
+    elif not (torch.is_grad_enabled() and points.requires_grad):
+        out = _C.gather_neighbors(points, table, None)  # nothing to differentiate: no autograd node
     else:
         out = _gather_neighbors.apply(points, table, None)
     return out if idx.ndim == 3 else out[:, :, 0, :]

@@ -22,5 +22,10 @@ if [ "$2" != "quick" ]; then
   python tools/bench_knn_shapes.py > $OUT/knn_shapes.jsonl 2> /dev/null
   python tools/bench_distributions.py > $OUT/distributions.jsonl 2> /dev/null
   python tools/bench_long_lists.py > $OUT/long_lists.jsonl 2> /dev/null
+  python tools/small_ops.py > $OUT/small_ops.txt 2> /dev/null
+  python tools/host_overhead.py > $OUT/host_overhead.txt 2> /dev/null
+  python tools/knn_small_sweep.py > $OUT/knn_small_sweep.jsonl 2> /dev/null
+  python tools/fps_plan_sweep.py > $OUT/fps_plan_sweep.txt 2> /dev/null
+  python tools/chamfer_probe.py 50 > $OUT/chamfer_probe.txt 2> /dev/null
 fi
 head -c 1500 $OUT/bench.json; echo; head -12 $OUT/kernel_stats.csv | cut -c1-100,240-330
