@@ -168,6 +168,11 @@ _SMALL = {  # name: (N, P1, P2, D, K, norm, l1, l2)
     "few_queries_long_cloud": (1, 7, 20000, 3, 8, 2, [6], [20000]),
     "many_queries_per_wave": (1, 40000, 100, 3, 4, 2, [39999], [100]),  # 3 queries per wave
     "identical_points": (1, 70, 300, 3, 8, 2, [70], [300]),
+    # long clouds: the wave-uniform gates are refreshed several times; on a lattice most candidates TIE with the gate
+    "k32_long_cloud_gates": (1, 5, 20000, 3, 32, 2, [5], [19999]),
+    "k4_long_lattice_gate_ties": (2, 40, 9000, 3, 4, 2, [40, 13], [9000, 8999]),
+    "k1_long_lattice_gate_ties_l1": (1, 70, 6000, 2, 1, 1, [70], [6000]),
+    "k8_identical_long": (1, 9, 5000, 3, 8, 2, [9], [5000]),
 }
 
 
@@ -186,7 +191,7 @@ def test_knn_small_batches(dev, oracle, monkeypatch, name, per_wave):
     p2 = cases.cloud(1901 + D + K, (N, P2, D))
     if "lattice" in name:
         p1, p2 = cases.lattice(1902, N, P1, D, levels=5), cases.lattice(1903, N, P2, D, levels=5)
-    if name == "identical_points":
+    if name in ("identical_points", "k8_identical_long"):
         p2[:] = np.float32(0.25)
     l1, l2 = np.array(l1), np.array(l2)
     monkeypatch.setenv("POINTOPS_DEBUG", "knn_small=1,knn_small_q=" + ("1" if per_wave == "one" else "2"))
