@@ -8,6 +8,7 @@
 // reduction torch kernels and one host sync here).  Fixed-shape tree reduction, so
 // the result is deterministic run to run.
 #include "common.h"
+#include "debug.h"
 
 namespace pointops {
 
@@ -504,14 +505,45 @@ __global__ __launch_bounds__(kWave) void chamfer_pair_grad_kernel(PairGrads in, 
 
 }  // namespace pointops
 
+// The two searches are independent until their results meet: when both go through the cell grid (big clouds: a dozen
+// latency-bound build launches each) the reverse direction runs on a side stream of its own, forked from and joined to
+// the caller's stream by events, with its own search workspace and distance buffer.  POINTOPS_DEBUG chamfer_overlap=0
+// keeps one stream.
+static bool pair_overlap(int64_t N, int64_t P1, int64_t P2, int64_t D) {
+  return pointops::debug_knob("chamfer_overlap", 1) != 0 && pointops_knn_uses_grid(N, P1, P2, D, 1, -1) &&
+         pointops_knn_uses_grid(N, P2, P1, D, 1, -1);
+}
+
+struct PairSide {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+static PairSide* pair_side() {  // per host thread and device; created on first use, never destroyed
+  static thread_local PairSide sides[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  PairSide* s = &sides[dev];
+  if (s->stream == nullptr) {
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      s->stream = nullptr;
+      return nullptr;
+    }
+  }
+  return s;
+}
+
 extern "C" size_t pointops_chamfer_pair_workspace_bytes(int64_t N, int64_t P1, int64_t P2, int64_t D, int F) {
   using namespace pointops;
   if (N <= 0) return 0;
-  const int64_t Pm = P1 > P2 ? P1 : P2;
   const size_t knn_a = pointops_knn_workspace_bytes(N, P1, P2, D, 1, -1), knn_b = pointops_knn_workspace_bytes(N, P2, P1, D, 1, -1);
   const size_t ch_a = pointops_chamfer_workspace_bytes(N, P1), ch_b = pointops_chamfer_workspace_bytes(N, P2);
-  return cp_align(knn_a > knn_b ? knn_a : knn_b) + cp_align(sizeof(float) * (size_t)(N * Pm)) +
-         cp_align(ch_a > ch_b ? ch_a : ch_b) + 2 * cp_align(sizeof(float) * (size_t)((1 + F) * N));
+  // (laid out for two concurrent searches whether or not they overlap)
+  return cp_align(knn_a) + cp_align(knn_b) + cp_align(sizeof(float) * (size_t)(N * P1)) +
+         cp_align(sizeof(float) * (size_t)(N * P2)) + cp_align(ch_a > ch_b ? ch_a : ch_b) +
+         2 * cp_align(sizeof(float) * (size_t)((1 + F) * N));
 }
 
 extern "C" int pointops_chamfer_pair_forward(const float* x, const float* y, const int64_t* x_lengths,
@@ -528,29 +560,46 @@ extern "C" int pointops_chamfer_pair_forward(const float* x, const float* y, con
   if (N == 0) return POINTOPS_OK;
   POINTOPS_REQUIRE(workspace != nullptr && workspace_bytes >= pointops_chamfer_pair_workspace_bytes(N, P1, P2, D, F),
                    "chamfer_pair_forward: workspace too small");
-  const int64_t Pm = P1 > P2 ? P1 : P2;
   const size_t knn_a = pointops_knn_workspace_bytes(N, P1, P2, D, 1, -1), knn_b = pointops_knn_workspace_bytes(N, P2, P1, D, 1, -1);
   const size_t ch_a = pointops_chamfer_workspace_bytes(N, P1), ch_b = pointops_chamfer_workspace_bytes(N, P2);
   char* w = (char*)workspace;
-  void* knn_ws = w;
-  w += cp_align(knn_a > knn_b ? knn_a : knn_b);
-  float* dists = (float*)w;
-  w += cp_align(sizeof(float) * (size_t)(N * Pm));
+  void* knn_ws_a = w;
+  w += cp_align(knn_a);
+  void* knn_ws_b = w;
+  w += cp_align(knn_b);
+  float* dists_a = (float*)w;
+  w += cp_align(sizeof(float) * (size_t)(N * P1));
+  float* dists_b = (float*)w;
+  w += cp_align(sizeof(float) * (size_t)(N * P2));
   void* ch_ws = w;
   w += cp_align(ch_a > ch_b ? ch_a : ch_b);
   float* rows_a = (float*)w;
   w += cp_align(sizeof(float) * (size_t)((1 + F) * N));
   float* rows_b = (float*)w;
-  int rc = pointops_knn_points_idx(x, y, x_lengths, y_lengths, N, P1, P2, D, norm, 1, -1, idx_xy, dists, knn_ws, knn_a,
-                                   stream_);
-  if (rc != POINTOPS_OK) return rc;
-  rc = pointops_chamfer_forward(dists, idx_xy, x_lengths, y_lengths, nullptr, N, P1, P2, F, x_feats, y_feats, C,
-                                abs_cosine, mean, rows_a, ch_ws, ch_a, stream_);
-  if (rc != POINTOPS_OK) return rc;
-  rc = pointops_knn_points_idx(y, x, y_lengths, x_lengths, N, P2, P1, D, norm, 1, -1, idx_yx, dists, knn_ws, knn_b,
+  hipStream_t main_stream = (hipStream_t)stream_;
+  PairSide* side = pair_overlap(N, P1, P2, D) ? pair_side() : nullptr;
+  void* stream_b = stream_;
+  if (side != nullptr) {
+    if (hipEventRecord(side->fork, main_stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess)
+      return check_launch("chamfer_pair_forward(fork)");
+    stream_b = (void*)side->stream;
+  }
+  // the reverse search first: on its own stream it overlaps everything the forward direction does
+  int rc = pointops_knn_points_idx(y, x, y_lengths, x_lengths, N, P2, P1, D, norm, 1, -1, idx_yx, dists_b, knn_ws_b, knn_b,
+                                   stream_b);
+  if (side != nullptr && hipEventRecord(side->join, side->stream) != hipSuccess) rc = check_launch("chamfer_pair_forward(join)");
+  const int rc_b = rc;
+  rc = pointops_knn_points_idx(x, y, x_lengths, y_lengths, N, P1, P2, D, norm, 1, -1, idx_xy, dists_a, knn_ws_a, knn_a,
                                stream_);
+  if (rc == POINTOPS_OK)
+    rc = pointops_chamfer_forward(dists_a, idx_xy, x_lengths, y_lengths, nullptr, N, P1, P2, F, x_feats, y_feats, C,
+                                  abs_cosine, mean, rows_a, ch_ws, ch_a, stream_);
+  // join before anything else can fail out: the caller's stream must not run ahead of the side stream's use of the workspace
+  if (side != nullptr && hipStreamWaitEvent(main_stream, side->join, 0) != hipSuccess)
+    return check_launch("chamfer_pair_forward(join)");
+  if (rc_b != POINTOPS_OK) return rc_b;
   if (rc != POINTOPS_OK) return rc;
-  rc = pointops_chamfer_forward(dists, idx_yx, y_lengths, x_lengths, nullptr, N, P2, P1, F, y_feats, x_feats, C,
+  rc = pointops_chamfer_forward(dists_b, idx_yx, y_lengths, x_lengths, nullptr, N, P2, P1, F, y_feats, x_feats, C,
                                 abs_cosine, mean, rows_b, ch_ws, ch_b, stream_);
   if (rc != POINTOPS_OK) return rc;
   PairOuts po;
