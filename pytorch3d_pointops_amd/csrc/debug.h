@@ -17,6 +17,7 @@
 //   knn_bwd_mode=a|t   knn backward grad_p2: device atomics / LDS tiles;  knn_bwd_split=S
 //   gather_bwd_mode=a|t, gather_bwd_split=S   the same for knn_gather's backward
 //   chamfer_overlap=0  one-call chamfer: the reverse search on the caller's stream instead of a side stream
+//   fps_small=0        FPS: clouds of up to 4096 points through the 16-wave cluster kernel instead of the 4-wave one
 //   fps_small_ppt=0    FPS clusters: never four points per lane for clouds above 4096 points;  fps_ppt=4|8|16 forces it
 //   fps_mode=0|1|2     FPS clusters: round-robin members / XCD-local members / XCD-local + L2 exchange
 //   fps_spin_limit=N   FPS exchange spin bound (tests force the timeout repair path with 0)

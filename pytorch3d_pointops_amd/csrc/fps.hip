@@ -448,6 +448,80 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Small clouds (<= 4096 points, D in {2,3}): ONE workgroup of FOUR waves per cloud -- a wave per SIMD.  Same
+// register-resident keys and LDS copy of the cloud as the single-workgroup path above, but a barrier of 4 waves
+// instead of 16 and, up to 1024 / 2048 points, a quarter / half of the arithmetic per iteration: 2 x 1024 points 0.84 ->
+// 0.44 us per iteration, 2 x 4096 0.85 -> 0.77 (the reference's example sizes; tools/fps_small.py).
+// ---------------------------------------------------------------------------
+constexpr int kFpsSmallBlock = 256;
+constexpr int kFpsSmallWaves = kFpsSmallBlock / kWave;
+
+template <int DT, int PPT>
+__global__ __launch_bounds__(kFpsSmallBlock) void fps_small_kernel(
+    const float* __restrict__ points, const int64_t* __restrict__ lengths, const int64_t* __restrict__ Ks,
+    const int64_t* __restrict__ start_idxs, int P, int max_K, int64_t* __restrict__ idxs) {
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  __shared__ double s_key2[2][kFpsSmallWaves];
+  __shared__ float s_pts[PPT * kFpsSmallBlock * DT];
+  int len = (int)lengths[n];
+  if (len > P) len = P;
+  int64_t kn64 = Ks[n];
+  int kn = (int)(kn64 < (int64_t)len ? kn64 : (int64_t)len);
+  if (kn > max_K) kn = max_K;
+  if (kn < 0) kn = 0;
+  int64_t* __restrict__ out = idxs + (int64_t)n * max_K;
+  for (int k = (kn > 0 ? kn : 0) + tid; k < max_K; k += kFpsSmallBlock) out[k] = -1;
+  if (len <= 0 || kn <= 0) return;
+  const float* __restrict__ pts = points + (int64_t)n * P * DT;
+  float px[PPT][DT];
+  double mk[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int p = tid + i * kFpsSmallBlock;
+    const bool valid = p < len;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      px[i][d] = valid ? pts[(int64_t)p * DT + d] : 0.0f;
+      s_pts[p * DT + d] = px[i][d];
+    }
+    mk[i] = __hiloint2double(__float_as_int(valid ? FLT_MAX : -1.0f), (int)(0xffffffffu - (unsigned)p));
+  }
+  int last = (int)start_idxs[n];
+  if (last < 0 || last >= len) last = 0;
+  if (tid == 0) out[0] = last;
+  __syncthreads();
+  for (int k = 1; k < kn; ++k) {
+    float c[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) c[d] = s_pts[last * DT + d];
+    double best = __hiloint2double(__float_as_int(-1.0f), 0);
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      float acc;
+      {
+        const float diff = c[0] - px[i][0];
+        acc = diff * diff;
+      }
+#pragma unroll
+      for (int d = 1; d < DT; ++d) {
+        const float diff = c[d] - px[i][d];
+        acc = acc + diff * diff;
+      }
+      const float m = fps_min(acc, __int_as_float(__double2hiint(mk[i])));
+      mk[i] = __hiloint2double(__float_as_int(m), __double2loint(mk[i]));
+      best = fps_max(best, mk[i]);
+    }
+    best = fps_wave_max(best);
+    if (lane == 0) s_key2[k & 1][wave] = best;
+    __syncthreads();
+    const double v = fps_row_max(s_key2[k & 1][lane & (kFpsSmallWaves - 1)]);  // every lane: the workgroup's maximum
+    last = __builtin_amdgcn_readfirstlane((int)(0xffffffffu - (unsigned)__double2loint(v)));
+    if (tid == 0) out[k] = last;
+  }
+}
+
 }  // namespace pointops
 
 using namespace pointops;
@@ -538,6 +612,23 @@ extern "C" int pointops_sample_farthest_points(const float* points, const int64_
 #define PO_LAUNCH(DT, FLAGS)                                                                      \
   hipLaunchKernelGGL((fps_kernel<DT>), dim3((unsigned)N), dim3(kFpsBlock), 0, stream, points, lengths, K, \
                      start_idxs, (int)P, (int)D, (int)max_K, idxs, min_dist_ws, FLAGS)
+  // small clouds: one four-wave workgroup per cloud
+  if ((D == 3 || D == 2) && P >= 1 && P <= 16 * kFpsSmallBlock && debug_knob("fps_small", 1) != 0) {
+#define PO_SMALL(DT, PPT)                                                                                          \
+  hipLaunchKernelGGL((fps_small_kernel<DT, PPT>), dim3((unsigned)N), dim3(kFpsSmallBlock), 0, stream, points, lengths, K, \
+                     start_idxs, (int)P, (int)max_K, idxs)
+    if (D == 3) {
+      if (P <= 4 * kFpsSmallBlock) PO_SMALL(3, 4);
+      else if (P <= 8 * kFpsSmallBlock) PO_SMALL(3, 8);
+      else PO_SMALL(3, 16);
+    } else {
+      if (P <= 4 * kFpsSmallBlock) PO_SMALL(2, 4);
+      else if (P <= 8 * kFpsSmallBlock) PO_SMALL(2, 8);
+      else PO_SMALL(2, 16);
+    }
+#undef PO_SMALL
+    return check_launch("sample_farthest_points(small)");
+  }
   // v2 (register-resident clusters) for D in {2,3}: up to PPT*1024 points per workgroup
   if ((D == 3 || D == 2) && P >= 1) {
     int resident = 0;

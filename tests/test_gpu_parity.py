@@ -505,9 +505,15 @@ def test_ball_query_grid_adversarial(dev, oracle, monkeypatch, name):
 
 
 # ------------------------------------------------------------------ FPS
+@pytest.mark.parametrize("kernel", ["auto", "clusters"])
 @pytest.mark.parametrize("name", sorted(cases.fps_cases()))
-def test_sample_farthest_points(dev, oracle, name):
+def test_sample_farthest_points(dev, oracle, monkeypatch, name, kernel):
+    """Reference goldens + oracle; "auto": clouds of up to 4096 points take the four-wave kernel (fps_small_kernel),
+    "clusters": the 16-wave cluster kernel they took before (POINTOPS_DEBUG fps_small=0)."""
     from pytorch3d_pointops_amd import _C
+
+    if kernel == "clusters":
+        monkeypatch.setenv("POINTOPS_DEBUG", "fps_small=0")
     from pytorch3d_pointops_amd.functions import masked_gather, sample_farthest_points
     from pytorch3d_pointops_amd.functions.sample_farthest_points import sample_farthest_points_naive
 
@@ -534,12 +540,12 @@ def test_fps_multi_workgroup_clusters(dev, oracle):
     ragged clouds share the clusters (persistent loop)."""
     from pytorch3d_pointops_amd import _C
 
-    for (N, P, D) in ((5, 10000, 3), (3, 40000, 3), (3, 9000, 2)):
+    for (N, P, D) in ((5, 10000, 3), (3, 40000, 3), (3, 9000, 2), (5, 4096, 3), (4, 3000, 2), (5, 1024, 3), (3, 700, 2)):
         pts = cases.cloud(1400 + P, (N, P, D))
         pts[0, 100:200] = pts[0, 0:100]  # duplicates -> ties on the running min-distance
-        lengths = np.array([P, P // 2 + 7, 4097, 5, P - 1][:N])
+        lengths = np.array([P, P // 2 + 7, min(4097, P), 5, P - 1][:N])
         K = np.array([64, 300, 17, 9, 128][:N])
-        start = np.array([0, 11, 4096, 4, P - 2][:N])
+        start = np.array([0, 11, min(4096, P - 1), 4, P - 2][:N])
         got = _C.sample_farthest_points(G(pts, dev), G(lengths, dev), G(K, dev), G(start, dev)).cpu().numpy()
         want = oracle.sample_farthest_points(pts, lengths, K, start)
         assert np.array_equal(got, want), (N, P, D)
