@@ -59,9 +59,17 @@ __global__ __launch_bounds__(kFpsBlock) void fps_kernel(
   if (kn > max_K) kn = max_K;
   if (kn < 0) kn = 0;
   int64_t* __restrict__ out = idxs + (int64_t)n * max_K;
-  // -1 padding beyond the samples this cloud produces
-  for (int k = (kn > 0 ? kn : 0) + tid; k < max_K; k += kFpsBlock) out[k] = -1;
-  if (len <= 0 || kn <= 0) return;
+  // -1 padding beyond the samples this cloud produces; a non-empty cloud always reports its start index, even with
+  // K[n] = 0 (sample_farthest_points_cpu.cpp:53-57 writes it before looking at K)
+  const int keep = len > 0 ? (kn > 1 ? kn : 1) : 0;
+  for (int k = keep + tid; k < max_K; k += kFpsBlock) out[k] = -1;
+  if (len <= 0) return;
+  if (kn <= 1) {
+    int first = (int)start_idxs[n];
+    if (first < 0 || first >= len) first = 0;
+    if (tid == 0) out[0] = first;
+    return;
+  }
 
   const float* __restrict__ pts = points + (int64_t)n * P * D;
   float* __restrict__ md = min_dist + (int64_t)n * P;
@@ -291,10 +299,17 @@ __global__ __launch_bounds__(kFpsBlock) void fps_cluster_kernel(
     if (kn > max_K) kn = max_K;
     if (kn < 0) kn = 0;
     int64_t* __restrict__ out = idxs + (int64_t)n * max_K;
+    const int keep = len > 0 ? (kn > 1 ? kn : 1) : 0;  // (the start index is reported even with K[n] = 0: cpu.cpp:53-57)
     if (member == 0) {
-      for (int k = (kn > 0 ? kn : 0) + tid; k < max_K; k += kFpsBlock) out[k] = -1;
+      for (int k = keep + tid; k < max_K; k += kFpsBlock) out[k] = -1;
     }
-    if (len <= 0 || kn <= 0) continue;
+    if (len <= 0) continue;
+    if (kn <= 1) {  // (uniform over the cloud's members)
+      int first = (int)start_idxs[n];
+      if (first < 0 || first >= len) first = 0;
+      if (member == 0 && tid == 0) out[0] = first;
+      continue;
+    }
 
     const float* __restrict__ pts = points + (int64_t)n * P * DT;
     // this lane's points: p = member*PPT*1024 + i*1024 + tid  (ascending in i); mk[i] = argmax key of point i:
@@ -472,8 +487,15 @@ __global__ __launch_bounds__(kFpsSmallBlock) void fps_small_kernel(
   if (kn > max_K) kn = max_K;
   if (kn < 0) kn = 0;
   int64_t* __restrict__ out = idxs + (int64_t)n * max_K;
-  for (int k = (kn > 0 ? kn : 0) + tid; k < max_K; k += kFpsSmallBlock) out[k] = -1;
-  if (len <= 0 || kn <= 0) return;
+  const int keep = len > 0 ? (kn > 1 ? kn : 1) : 0;  // (the start index is reported even with K[n] = 0: cpu.cpp:53-57)
+  for (int k = keep + tid; k < max_K; k += kFpsSmallBlock) out[k] = -1;
+  if (len <= 0) return;
+  if (kn <= 1) {
+    int first = (int)start_idxs[n];
+    if (first < 0 || first >= len) first = 0;
+    if (tid == 0) out[0] = first;
+    return;
+  }
   const float* __restrict__ pts = points + (int64_t)n * P * DT;
   float px[PPT][DT];
   double mk[PPT];

@@ -551,6 +551,22 @@ def test_fps_multi_workgroup_clusters(dev, oracle):
         assert np.array_equal(got, want), (N, P, D)
 
 
+@pytest.mark.parametrize("knob", ["", "fps_small=0"])
+def test_fps_zero_k_cloud_reports_its_start_index(dev, oracle, monkeypatch, knob):
+    """A cloud with K[n] = 0 in a batch whose max K is positive: the reference's CPU kernel writes the start index
+    into slot 0 BEFORE it looks at K (sample_farthest_points_cpu.cpp:53-57), so the row is [start, -1, ...]; an empty
+    cloud stays all -1.  (Found by tests/test_fuzz_small_gpu.py: rounds 1-2 returned -1 there.)"""
+    from pytorch3d_pointops_amd import _C
+
+    monkeypatch.setenv("POINTOPS_DEBUG", knob)
+    for P in (500, 6000, 20000):  # four-wave kernel / one cluster workgroup / several
+        pts = cases.cloud(2300 + P, (4, P, 3))
+        L, K, S = np.array([P, P - 7, 0, 33]), np.array([5, 0, 3, 1]), np.array([1, 9, 0, 32])
+        got = _C.sample_farthest_points(G(pts, dev), G(L, dev), G(K, dev), G(S, dev)).cpu().numpy()
+        assert np.array_equal(got, oracle.sample_farthest_points(pts, L, K, S))
+        assert got[1].tolist() == [9, -1, -1, -1, -1] and got[2].tolist() == [-1] * 5 and got[3].tolist() == [32, -1, -1, -1, -1]
+
+
 def test_fps_int_and_list_K_and_random_start(dev):
     from pytorch3d_pointops_amd.functions import sample_farthest_points
 
