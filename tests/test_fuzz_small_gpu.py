@@ -150,3 +150,143 @@ def test_fuzz_ball_grid_and_fps_clusters(dev, oracle, monkeypatch, seed):
         want = oracle.sample_farthest_points(pts, L, Kt, S)
         got = _C.sample_farthest_points(_G(pts, dev), _G(L, dev), _G(Kt, dev), _G(S, dev)).cpu().numpy()
         assert np.array_equal(got, want), dict(N=N, P=P, D=D, L=L.tolist(), K=Kt.tolist(), S=S.tolist())
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_backward_and_gather(dev, oracle, monkeypatch, seed):
+    """knn_points_backward (the KNN table of a real search, and a ball-query table with -1 padding) in its three
+    forms -- LDS tiles / device atomics by shape, forced atomics, the deterministic inverted table -- against the oracle:
+    grad_p1 bit-exact (register sums in k order), grad_p2 within 1e-5 (bit-exact in the deterministic form);
+    knn_gather / masked_gather forward against their numpy restatements."""
+    from oracle import oracle as O
+    from pytorch3d_pointops_amd import _C
+
+    rng = np.random.default_rng(600 + seed)
+    for it in range(12):
+        N, P1, P2 = int(rng.integers(1, 5)), int(rng.integers(1, 900)), int(rng.integers(1, 2500))
+        D, K, norm = int(rng.integers(1, 7)), int(rng.choice([1, 3, 8, 16, 33])), int(rng.integers(1, 3))
+        lattice = rng.random() < 0.3
+        p1, p2 = _cloud(rng, (N, P1, D), lattice), _cloud(rng, (N, P2, D), lattice)
+        l1, l2 = _lengths(rng, N, P1), _lengths(rng, N, P2)
+        if it % 2 == 0:
+            idx, _ = oracle.knn_points_idx(p1, p2, l1, l2, norm, K)
+        else:
+            idx, _ = oracle.ball_query(p1, p2, l1, l2, K, 0.3)
+            norm = 2
+        g = rng.standard_normal((N, P1, K)).astype(np.float32)
+        g[rng.random((N, P1, K)) < 0.2] = 0.0
+        w1, w2 = oracle.knn_points_backward(p1, p2, l1, l2, idx, norm, g)
+        for knob, det in (("", False), ("knn_bwd_mode=a", False), ("knn_bwd_mode=t", False), ("", True)):
+            monkeypatch.setenv("POINTOPS_DEBUG", knob)
+            g1, g2 = _C.knn_points_backward(_G(p1, dev), _G(p2, dev), _G(l1, dev), _G(l2, dev), _G(idx, dev), norm,
+                                            _G(g, dev), deterministic=det)
+            what = dict(N=N, P1=P1, P2=P2, D=D, K=K, norm=norm, knob=knob, det=det, it=it)
+            assert np.array_equal(_bits(g1.cpu().numpy()), _bits(w1)), what
+            if det:
+                assert np.array_equal(_bits(g2.cpu().numpy()), _bits(w2)), what
+            else:
+                assert np.allclose(g2.cpu().numpy(), w2, rtol=1e-5, atol=1e-5), what
+        monkeypatch.delenv("POINTOPS_DEBUG")
+        U = int(rng.integers(1, 9))
+        x = _cloud(rng, (N, P2, U), False)
+        if it % 2 == 0:
+            out = _C.gather_neighbors(_G(x, dev), _G(idx, dev), _G(l2, dev))
+            assert np.array_equal(out.cpu().numpy(), O.knn_gather(x, idx, l2)), dict(it=it, U=U)
+        else:
+            out = _C.gather_neighbors(_G(x, dev), _G(idx, dev), None)
+            assert np.array_equal(out.cpu().numpy(), O.masked_gather(x, idx)), dict(it=it, U=U)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_wide_families_and_packing(dev, oracle, seed):
+    """Feature-space D and long lists off the grid (families 0 / 2 by shape), the K > 64 grid search, packed <-> padded
+    and sample_pdf on random ragged inputs, against the oracle."""
+    from pytorch3d_pointops_amd import _C
+
+    rng = np.random.default_rng(700 + seed)
+    for it in range(10):
+        N, P1, P2 = int(rng.integers(1, 4)), int(rng.integers(1, 400)), int(rng.integers(1, 1500))
+        D, K = int(rng.choice([1, 3, 4, 9, 16, 33, 70])), int(rng.choice([1, 5, 32, 33, 64, 65, 100, 130]))
+        norm = int(rng.integers(1, 3))
+        lattice = rng.random() < 0.3
+        p1, p2 = _cloud(rng, (N, P1, D), lattice), _cloud(rng, (N, P2, D), lattice)
+        l1, l2 = _lengths(rng, N, P1), _lengths(rng, N, P2)
+        oi, od = oracle.knn_points_idx(p1, p2, l1, l2, norm, K)
+        versions = [-1, 0] + ([3] if D <= 3 and K <= 128 else [])
+        for v in versions:
+            i, d = _C.knn_points_idx(_G(p1, dev), _G(p2, dev), _G(l1, dev), _G(l2, dev), norm, K, v)
+            what = dict(N=N, P1=P1, P2=P2, D=D, K=K, norm=norm, lattice=lattice, version=v, l1=l1.tolist(), l2=l2.tolist())
+            assert np.array_equal(i.cpu().numpy(), oi), what
+            assert np.array_equal(_bits(d.cpu().numpy()), _bits(od)), what
+    for it in range(10):
+        B, D = int(rng.integers(1, 7)), int(rng.integers(1, 6))
+        sizes = rng.integers(0, 300, B)
+        first = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        F = int(sizes.sum())
+        if F == 0:
+            continue
+        M = int(max(sizes.max(), 1))
+        packed = rng.standard_normal((F, D)).astype(np.float32)
+        want = oracle.packed_to_padded(packed, first, M)
+        got = _C.packed_to_padded(_G(packed, dev), _G(first, dev), M)
+        assert np.array_equal(_bits(got.cpu().numpy()), _bits(want)), dict(B=B, D=D, sizes=sizes.tolist())
+        back = _C.padded_to_packed(got, _G(first, dev), F)
+        assert np.array_equal(_bits(back.cpu().numpy()), _bits(oracle.padded_to_packed(want, first, F)))
+        assert np.array_equal(_bits(back.cpu().numpy()), _bits(packed))
+    for it in range(8):
+        batch, nb, ns = int(rng.integers(1, 40)), int(rng.integers(1, 70)), int(rng.integers(1, 90))
+        bins = np.sort(rng.random((batch, nb + 1), dtype=np.float32), axis=1)
+        w = rng.random((batch, nb), dtype=np.float32)
+        w[rng.random((batch, nb)) < 0.2] = 0.0
+        u = rng.random((batch, ns), dtype=np.float32)
+        eps = float(rng.choice([1e-5, 1e-2, 0.0]))
+        want = oracle.sample_pdf(bins, w, u.copy(), eps)
+        out = _G(u.copy(), dev)
+        _C.sample_pdf(_G(bins, dev), _G(w, dev), out, eps)
+        assert np.array_equal(_bits(out.cpu().numpy()), _bits(want)), dict(batch=batch, nb=nb, ns=ns, eps=eps)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_chamfer_native_vs_composed(dev, monkeypatch, seed):
+    """The one-call bidirectional chamfer against the composed path (knn_points + knn_gather + torch reductions) on
+    random ragged batches, reductions, norms and optional normals: losses and all gradients."""
+    import pytorch3d_pointops_amd.functions.chamfer as ch
+
+    rng = np.random.default_rng(800 + seed)
+    for it in range(8):
+        N, P1, P2 = int(rng.integers(1, 6)), int(rng.integers(2, 900)), int(rng.integers(2, 1200))
+        l1 = np.maximum(_lengths(rng, N, P1), 1)
+        l2 = np.maximum(_lengths(rng, N, P2), 1)
+        with_normals = rng.random() < 0.5
+        br = [None, "mean", "sum"][int(rng.integers(0, 3))]
+        pr = ["mean", "sum"][int(rng.integers(0, 2))]
+        norm = int(rng.integers(1, 3))
+        abs_cos = bool(rng.random() < 0.5)
+        base = dict(x=_cloud(rng, (N, P1, 3), False), y=_cloud(rng, (N, P2, 3), False))
+        if with_normals:
+            base.update(xn=_cloud(rng, (N, P1, 3), False) - np.float32(0.5), yn=_cloud(rng, (N, P2, 3), False) - np.float32(0.5))
+
+        def run():
+            t = {k: _G(v, dev).requires_grad_(True) for k, v in base.items()}
+            kw = dict(x_features={"normals": t["xn"]}, y_features={"normals": t["yn"]}, feature_names=["normals"]) \
+                if with_normals else {}
+            loss, lf = ch.chamfer_distance(t["x"], t["y"], x_lengths=_G(l1, dev), y_lengths=_G(l2, dev), batch_reduction=br,
+                                           point_reduction=pr, norm=norm, abs_cosine=abs_cos, **kw)
+            total = loss.sum() * 1.25 + (lf["normals"].sum() * 0.5 if with_normals else 0.0)
+            total.backward()
+            return [loss.detach()] + ([lf["normals"].detach()] if with_normals else []), {k: v.grad for k, v in t.items()}
+
+        a = run()
+        with monkeypatch.context() as m:
+            m.setattr(ch, "_fused_direction_ok", lambda *args, **kw: False)
+            b = run()
+        what = dict(N=N, P1=P1, P2=P2, br=br, pr=pr, norm=norm, normals=with_normals, l1=l1.tolist(), l2=l2.tolist())
+        for u, v in zip(a[0], b[0]):
+            assert u.shape == v.shape, what
+            assert np.allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-5, atol=1e-6), what
+        for k in base:
+            # (normals of length ~0 give cosine gradients of size ~1/|n| with cancellation inside: the absolute term scales
+            # with the largest gradient of the tensor)
+            u, v = a[1][k].cpu().numpy(), b[1][k].cpu().numpy()
+            tol = 2e-5 * np.abs(v) + 2e-6 * max(1.0, float(np.abs(v).max()))
+            assert (np.abs(u - v) <= tol).all(), (k, float((np.abs(u - v) - tol).max()), what)
