@@ -199,7 +199,8 @@ def _scratch(nbytes: int, dev):
     """Workspace for one call.  Small ones (<= 4 MiB: the sliced brute-force scans of small batches) come from a grow-only
     buffer per (device, stream): every user enqueues on that stream, in order, so the buffer can be handed out again at
     once and a small call saves an allocator round trip (~2 us).  Big ones are allocated per call."""
-    if nbytes > (4 << 20):
+    if nbytes > (4 << 20) or torch.cuda.is_current_stream_capturing():
+        # (inside a HIP-graph capture the buffer must belong to the graph's private pool: graphs.py)
         return torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     key = (dev.index, _stream())
     buf = _SCRATCH.get(key)
@@ -260,7 +261,8 @@ def knn_points_idx(p1, p2, lengths1, lengths2, norm: int, K: int, version: int =
         dists = torch.empty((N, P1, K), dtype=torch.float32, device=dev)
         ws_bytes = _lib.pointops_knn_workspace_bytes(N, P1, P2, D, K, version)
         reuse = 0
-        if _GRID_CACHE_ON and ws_bytes and _lib.pointops_knn_uses_grid(N, P1, P2, D, int(K), int(version)):
+        if _GRID_CACHE_ON and ws_bytes and _lib.pointops_knn_uses_grid(N, P1, P2, D, int(K), int(version)) \
+                and not torch.cuda.is_current_stream_capturing():  # (a captured call must not bake a reuse level in)
             ws, reuse = _grid_workspace(p1, p2, lengths1, lengths2, (N, P1, P2, D, int(K), int(version)), ws_bytes, dev)
         else:
             ws = _scratch(ws_bytes, dev) if ws_bytes else None
@@ -408,7 +410,7 @@ def ball_query(p1, p2, lengths1, lengths2, K: int, radius: float):
 
 
 # reference: csrc/sample_farthest_points/sample_farthest_points.h:55-76
-def sample_farthest_points(points, lengths, K, start_idxs):
+def sample_farthest_points(points, lengths, K, start_idxs, max_K=None):
     dev = _require_gpu(points, lengths, K, start_idxs)
     if points.dtype != torch.float32:
         raise RuntimeError("expected scalar type Float for points")
@@ -420,8 +422,11 @@ def sample_farthest_points(points, lengths, K, start_idxs):
     N, P, D = points.shape
     if lengths.shape != (N,) or K.shape != (N,) or start_idxs.shape != (N,):
         raise RuntimeError("sample_farthest_points: lengths, K and start_idxs must have shape (N,)")
-    # host sync, as in the reference (sample_farthest_points.cu:132)
-    max_K = int(K.max().item()) if N > 0 else 0
+    # host sync, as in the reference (sample_farthest_points.cu:132) -- unless the caller knows the maximum (an int or a
+    # list K: no device-to-host read, and the call can be captured into a HIP graph)
+    if max_K is None:
+        max_K = int(K.max().item()) if N > 0 else 0
+    max_K = int(max_K) if N > 0 else 0
     with _on(dev):
         idxs = torch.empty((N, max_K), dtype=torch.int64, device=dev)
         ws_bytes = _lib.pointops_fps_workspace_bytes(N, P, max_K)

@@ -40,6 +40,7 @@ def sample_farthest_points(
     are -1 and points 0.0 beyond ``min(lengths[n], K[n])``.  Indices are computed
     without autograd; the points come from a differentiable gather.
     """
+    known_max = K if isinstance(K, int) else max(K) if isinstance(K, (list, tuple)) and len(K) else None
     lengths, K = _per_cloud(points, lengths, K, "A value in lengths was too large.")
     points = as_f32(points)
     start_idxs = torch.zeros_like(lengths)
@@ -51,7 +52,7 @@ def sample_farthest_points(
         if torch.compiler.is_compiling():
             idx = torch.ops.pointops_amd.sample_farthest_points(points, lengths, K, start_idxs)
         else:
-            idx = _C.sample_farthest_points(points, lengths, K, start_idxs)
+            idx = _C.sample_farthest_points(points, lengths, K, start_idxs, max_K=known_max)
     sampled_points = masked_gather(points, idx)
     return sampled_points, idx
 
