@@ -19,11 +19,19 @@ def main():
     out_dir = os.path.join(B.LIB_DIR, "variants")
     os.makedirs(out_dir, exist_ok=True)
     os.makedirs(os.path.join(B.OBJ_DIR, "variants"), exist_ok=True)  # (build/variants/ is .gpurunignore'd)
-    obj = os.path.join(B.OBJ_DIR, "variants", f"{unit}.{name}.o")
-    subprocess.check_call([B.HIPCC] + B.CXXFLAGS + flags + ["-c", os.path.join(B.CSRC, unit), "-o", obj])
-    objs = [o for o in sorted(glob.glob(os.path.join(B.OBJ_DIR, "*.hip.o"))) if os.path.basename(o) != unit + ".o"]
+    units = unit.split(",")  # (templates without the run-word parameter are instantiated in knn_grid_dN.hip AND knn_grid_dNw.hip:
+    new_objs = []            # the linker keeps one copy, so a flag that changes them must reach both units)
+    procs = []
+    for u in units:
+        obj = os.path.join(B.OBJ_DIR, "variants", f"{u}.{name}.o")
+        procs.append(subprocess.Popen([B.HIPCC] + B.CXXFLAGS + flags + ["-c", os.path.join(B.CSRC, u), "-o", obj]))
+        new_objs.append(obj)
+    if any(p.wait() != 0 for p in procs):
+        raise SystemExit("compile failed")
+    skip = {u + ".o" for u in units}
+    objs = [o for o in sorted(glob.glob(os.path.join(B.OBJ_DIR, "*.hip.o"))) if os.path.basename(o) not in skip]
     lib = os.path.join(out_dir, f"libpointops_amd_{name}.so")
-    subprocess.check_call([B.HIPCC, f"--offload-arch={B.ARCH}", "-shared", "-fPIC", "-o", lib] + objs + [obj])
+    subprocess.check_call([B.HIPCC, f"--offload-arch={B.ARCH}", "-shared", "-fPIC", "-o", lib] + objs + new_objs)
     print(lib)
 
 
