@@ -17,9 +17,10 @@ constexpr int kCoarseMax = 1024;     // micro-bins (and bins) per cloud and set 
 constexpr int kCrowdedMax = 64;      // crowded coarse bins listed per cloud and set (further ones: one workgroup each)
 constexpr int kFineLogMax = 12;      // cells per bin <= 4096
 constexpr int kOrderG = 16, kOrderBins = kOrderG * kOrderG * kOrderG;  // ball query: coarse cells of the scan-mode query order
-constexpr int kSortedPad = 8;        // records of padding behind every cloud's sorted array: record P2 is a NaN
+constexpr int kSortedPad = 32;       // records of padding behind every cloud's sorted array: record P2 is a NaN
                                      // sentinel (never a candidate); group loads of the lane searches may run
-                                     // up to 7 records past a run's end and stay inside the cloud's array
+                                     // up to 7 records past a run's end (G x stride - 1 in the strided walk of the radius-2 pass)
+                                     // and stay inside the cloud's array
 
 struct GridCloud {
   float lo[3];

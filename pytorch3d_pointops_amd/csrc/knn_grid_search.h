@@ -83,7 +83,10 @@ struct LaneCfg {
 constexpr int kRunBitsStd = 11, kRunBitsBig = 8;
 constexpr int64_t kGridMaxPoints = (1LL << (32 - kRunBitsStd)) - 16, kGridMaxPointsBig = (1LL << (32 - kRunBitsBig)) - 16;
 
-template <int D, int KC, int NORM, int ROWS, int RB>
+// STRIDE > 1: the lane takes every STRIDE-th record of its runs (the caller has shifted each run's start by the lane's
+// rank among the STRIDE lanes that share the runs and shortened its length by as much): record u of a group sits
+// 16 STRIDE u bytes behind the group's offset, and the STRIDE lanes' gathers fall into the same 64-byte segments.
+template <int D, int KC, int NORM, int ROWS, int RB, int STRIDE = 1>
 __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const unsigned* rows, int lane,
                                           double* s_queue, float qx, float qy, float qz, unsigned thr0,
                                           TopKF64<KC>& top) {
@@ -93,7 +96,8 @@ __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const un
   constexpr int kQueueLds = Cfg::kQueueLds;
   constexpr int kSub = Cfg::kSub;
   constexpr int G = Cfg::kGroup;
-  constexpr int kGroupBytes = G * 16;
+  constexpr int kGroupBytes = G * 16 * STRIDE;
+  static_assert(G * STRIDE <= kSortedPad, "a masked tail reads up to G * STRIDE records past its run");
   constexpr int kRunBits = RB, kRunMax = (1 << RB) - 1;
   double* const qbase = s_queue + lane;
   int rowi = lane + 2 * kGridWave;  // entry of `rows` after the prefetched one
@@ -118,7 +122,7 @@ __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const un
     }
   };
   auto record = [&](unsigned o, int u) __attribute__((always_inline)) -> float4 {
-    return *(const float4*)(spb + o + (unsigned)(16 * u));  // saddr + 32-bit voffset + immediate
+    return *(const float4*)(spb + o + (unsigned)(16 * STRIDE * u));  // saddr + 32-bit voffset + immediate
   };
 
   unsigned thr = thr0;
@@ -147,7 +151,7 @@ __device__ __forceinline__ void lane_walk(const char* __restrict__ spb, const un
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < kSub; ++t) {
-      const bool valid = 16 * (u0 + t) < crem;
+      const bool valid = 16 * STRIDE * (u0 + t) < crem;
       if (kUseQueue) {
         if (valid && __float_as_uint(dd[t]) <= thr) {
           s_queue[qn] = TopKF64<KC>::make(dd[t], ii[t]);
@@ -331,25 +335,28 @@ __global__ __launch_bounds__(kGridWave, KC > 32 ? 2 : 1) void knn_grid_lane_kern
 // pass 5b: radius-2 search for the queries pass 5 could not certify (~1 % of a cloud).
 // FOUR lanes share a query: the 25 (y, z) rows of the 5x5x5 cell cube around the query's
 // cell are dealt round-robin (nearest rows first) to the quad's lanes, each lane walks its
-// <= 7 contiguous runs (per-lane 16-byte gathers, eight in flight per pipeline stage, stale-threshold
-// queue, sorting-network merges), and two quad-permute exchange steps merge the four sorted lists,
-// after which every lane of the quad holds the cube's KC best.  (Kernel time at cfg2 with 4 / 8 / 16
+// <= 7 contiguous runs with the lane search's own walk (lane_walk: packed run words, groups of four
+// records behind one offset, stale-threshold queue, sorting-network merges), and two quad-permute exchange
+// steps merge the four sorted lists, after which every lane of the quad holds the cube's KC best.  (Kernel time at cfg2 with 4 / 8 / 16
 // lanes per query: 83 / 96 / 97-107 us in round 1, 63 / 67 / 69 us with this round's kernel (mirror DPP steps for
 // the wider merges) -- the pass is throughput-bound, not bound by one wave's chain,
 // so fewer, longer lanes win.)  The cube grows from 3x3x3 only past the faces that an ESTIMATE of the
 // KC-th distance reaches.  The same rigorous face bound decides; what is still uncertified (far-away
 // queries) goes to the expanding wave search.
 // ---------------------------------------------------------------------------
-constexpr int kQuadLanes = 4;  // lanes per query
-constexpr int kQuadRows = (25 + kQuadLanes - 1) / kQuadLanes;
+#ifndef POINTOPS_QUAD_LANES
+#define POINTOPS_QUAD_LANES 4
+#endif
+constexpr int kQuadLanes = POINTOPS_QUAD_LANES;  // lanes per query (4, or 8: a third merge step over row_half_mirror)
+static_assert(kQuadLanes == 4 || kQuadLanes == 8, "lanes per query");
+constexpr int kQuadRows = 25;  // every lane of the quad lists every row of the cube and takes every fourth record of it
 constexpr int kQuadQueries = kGridWave / kQuadLanes;
-constexpr int kQuadFetch = 8;  // gathers in flight per lane and pipeline stage (4: 76 us, 16: 104 us instead of 65 us)
 constexpr int kQuadMaxRecords = 1024;  // per lane of the quad
 __device__ constexpr signed char kQuadDy[32] = {0, 0, 0, -1, 1, -1, -1, 1, 1, 0, 0, -2, 2, -1, 1, -1, 1, -2, -2, 2, 2, -2, -2, 2, 2, 0, 0, 0, 0, 0, 0, 0};
 __device__ constexpr signed char kQuadDz[32] = {0, -1, 1, 0, 0, -1, 1, -1, 1, -2, 2, 0, 0, -2, -2, 2, 2, -1, 1, -1, 1, -2, 2, -2, 2, 0, 0, 0, 0, 0, 0, 0};
 
 // DPP controls: quad_perm [1,0,3,2] (lane ^ 1), quad_perm [2,3,0,1] (lane ^ 2)
-constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E;
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141;  // (row_half_mirror: lane i <-> 7 - i of its eight)
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
@@ -375,19 +382,19 @@ __device__ __forceinline__ void dpp_merge(TopKF64<KC>& top) {
 
 // (second launch bound: the 32-slot kernel needs 259 registers without it, three more than two waves per SIMD allow:
 // 186 -> 138 us at the cfg2 size)
-template <int D, int KC, int NORM>
+template <int D, int KC, int NORM, int RB>
 __global__ __launch_bounds__(kGridWave, KC >= 32 ? 2 : 1) void knn_grid_quad_kernel(
     const float* __restrict__ p1, const GridCloud* __restrict__ clouds, const float* __restrict__ edges,
     const int* __restrict__ cell_start, const float4* __restrict__ sorted, const int* __restrict__ fb_count,
     const int* __restrict__ fb_list, const unsigned* __restrict__ fb_kth, int* __restrict__ fb3_count,
     int* __restrict__ fb3_list, int* __restrict__ box_count, int* __restrict__ box_list, int cell_cap, int P1, int P2,
     int K, int64_t* __restrict__ idxs, float* __restrict__ dists) {
-  constexpr bool kUseQueue = KC >= 8;
-  constexpr int kQueueCap = KC < 16 ? KC : 16;
-  constexpr int kSub = 4;
-  static_assert(kQuadFetch % kSub == 0, "fetch groups are processed four candidates at a time");
+  constexpr bool kUseQueue = LaneCfg<KC>::kUseQueue;
+  constexpr int kQueueCap = LaneCfg<KC>::kQueueLds;
+  constexpr int kRunBits = RB, kRunMax = (1 << RB) - 1;
   __shared__ double s_queue[kUseQueue ? kQueueCap * kGridWave : 1];
-  __shared__ int2 s_rows[kQuadRows][kGridWave];
+  __shared__ unsigned s_rows[kQuadRows + 1][kGridWave];  // the lane's non-empty runs as packed words, zero-terminated
+  unsigned* const rows = &s_rows[0][0];
 
   const int n = blockIdx.y;
   const int cnt = fb_count[n];
@@ -429,100 +436,50 @@ __global__ __launch_bounds__(kGridWave, KC >= 32 ? 2 : 1) void knn_grid_quad_ker
     const float lb = box_lower_bound<NORM>(g, ed, qx, qy, qz, X0, X1, Y0, Y1, Z0, Z1, whole);
     const unsigned thr0 = seed_threshold(lb, whole);
 
+    // The quad's lanes SHARE every row of the cube: lane `sub` takes the records sub, sub + 4, sub + 8, ... of each of
+    // the <= 25 contiguous runs (nearest rows first), so the four gathers of a quad fall into the same 64-byte segment and
+    // the quad's lanes finish together.  Until round 3 the rows were DEALT to the lanes: the 64 lanes of a wave then
+    // gathered from 64 different lines per instruction, and the vector L1 serves about one such lane-request per clock
+    // and CU -- 87 000 cycles of walk per wave, whatever the cursor logic, the selection or the lanes per query cost
+    // (profiles/r03_lane_experiments.md, r03_quad_stamps.txt).  The walk and the selection are the lane search's
+    // (lane_walk with a record stride of four: packed run words, groups behind one offset, masked tails, stale-threshold
+    // queue).
+    bool overlong = false;
+    {
+      int cnt = 0;  // rows written so far, as an element offset into s_rows
+      int total = 0;  // records of the whole cube
 #pragma unroll
-    for (int j = 0; j < kQuadRows; ++j) {
-      const int rr = sub + kQuadLanes * j;  // table entries >= 25 do not exist
-      const int z = cz + kQuadDz[rr], y = cy + kQuadDy[rr];
-      int2 se = make_int2(0, 0);
-      if (active && rr < 25 && z >= Z0 && z <= Z1 && y >= Y0 && y <= Y1) {
-        const int rowbase = (z * g.G[1] + y) * g.G[0];
-        se.x = cstart[rowbase + X0];
-        se.y = cstart[rowbase + X1 + 1];
-      }
-      s_rows[j][lane] = se;
-    }
-    // a quad whose cube holds an over-full cell does not walk it lane by lane: the box search (which sees the
-    // refined cell's inside) takes the query
-    int mine = 0;
-#pragma unroll
-    for (int j = 0; j < kQuadRows; ++j) mine += s_rows[j][lane].y - s_rows[j][lane].x;
-    int bigq = mine > kQuadMaxRecords ? 1 : 0;  // OR over the quad, outside any divergent branch (a DPP read of an
-    bigq |= __builtin_amdgcn_mov_dpp(bigq, kDppXor1, 0xf, 0xf, true);  // inactive lane returns 0)
-    bigq |= __builtin_amdgcn_mov_dpp(bigq, kDppXor2, 0xf, 0xf, true);
-    const bool big = bigq != 0;
-    if (big) {
-#pragma unroll
-      for (int j = 0; j < kQuadRows; ++j) s_rows[j][lane] = make_int2(0, 0);
-    }
-    int r = 0;
-    int cur = s_rows[0][lane].x, end = s_rows[0][lane].y;
-    auto next_record = [&]() -> int {
-      while (cur >= end && r < kQuadRows - 1) {
-        ++r;
-        const int2 se = s_rows[r][lane];
-        cur = se.x;
-        end = se.y;
-      }
-      return cur < end ? cur++ : P2;  // exhausted: the NaN sentinel record
-    };
-
-    TopKF64<KC> top;
-    top.init();
-    unsigned thr = thr0;
-    int qn = lane;
-    auto flush = [&]() {
-      double qk[kQueueCap];
-#pragma unroll
-      for (int t = 0; t < kQueueCap; ++t) qk[t] = qbase[t * kGridWave];
-#pragma unroll
-      for (int t = 0; t < kQueueCap; ++t) qbase[t * kGridWave] = TopKF64<KC>::empty();
-      bitonic_sort<kQueueCap>(qk);
-#pragma unroll
-      for (int t = 0; t < kQueueCap; ++t) top.key[KC - 1 - t] = kmin(top.key[KC - 1 - t], qk[t]);
-      bitonic_merge<KC>(top.key);
-      qn = lane;
-      thr = min(top.worst_bits(), thr0);
-    };
-    auto fetch = [&](float4 (&c)[kQuadFetch]) -> bool {
-      int a[kQuadFetch];
-#pragma unroll
-      for (int u = 0; u < kQuadFetch; ++u) a[u] = next_record();
-#pragma unroll
-      for (int u = 0; u < kQuadFetch; ++u) c[u] = sp[a[u]];  // unconditional: exhausted lanes read the sentinel
-      return a[0] != P2;
-    };
-    float4 c[kQuadFetch];
-    bool more = fetch(c);
-    while (__any(more)) {
-      float4 nxt[kQuadFetch];
-      const bool more_next = fetch(nxt);
-#pragma unroll
-      for (int u0 = 0; u0 < kQuadFetch; u0 += kSub) {
-#pragma unroll
-        for (int u = u0; u < u0 + kSub; ++u) {
-          const float d = point_dist<D, NORM>(qx, qy, qz, c[u]);  // sentinel: NaN, above every threshold
-          if (kUseQueue) {
-            if (__float_as_uint(d) <= thr) {
-              s_queue[qn] = TopKF64<KC>::make(d, __float_as_int(c[u].w));
-              qn += kGridWave;
-            }
-          } else if (__float_as_uint(d) <= min(top.worst_bits(), thr0)) {
-            top.insert(TopKF64<KC>::make(d, __float_as_int(c[u].w)));
+      for (int rr = 0; rr < kQuadRows; ++rr) {
+        const int z = cz + kQuadDz[rr], y = cy + kQuadDy[rr];
+        if (active && z >= Z0 && z <= Z1 && y >= Y0 && y <= Y1) {
+          const int rowbase = (z * g.G[1] + y) * g.G[0];
+          const int s = cstart[rowbase + X0], e = cstart[rowbase + X1 + 1];
+          overlong = overlong || e - s > kRunMax;
+          total += e - s;
+          if (e - s > sub) {  // (the lane's share of the row: records s + sub, s + sub + 4, ... below e)
+            rows[lane + cnt] = ((unsigned)(s + sub) << kRunBits) | (unsigned)min(e - s - sub, kRunMax);
+            cnt += kGridWave;
           }
         }
-        if (kUseQueue) {
-          if (__any(qn > lane + (kQueueCap - kSub) * kGridWave)) flush();
-        }
       }
+      // a quad whose cube holds an over-full cell (or a run longer than the packed length field) does not walk it:
+      // the box search (which sees the refined cell's inside and splits runs) takes the query
+      overlong = overlong || total > kQuadLanes * kQuadMaxRecords;  // (the same for the four lanes: no exchange needed)
+      if (overlong) cnt = 0;
 #pragma unroll
-      for (int u = 0; u < kQuadFetch; ++u) c[u] = nxt[u];
-      more = more_next;
+      for (int r = 0; r <= kQuadRows; ++r) {
+        if (r * kGridWave >= cnt) s_rows[r][lane] = 0u;
+      }
     }
-    if (kUseQueue) flush();
+    const bool big = overlong;
+    TopKF64<KC> top;
+    top.init();
+    lane_walk<D, KC, NORM, kQuadRows, RB, kQuadLanes>((const char*)sp, rows, lane, s_queue, qx, qy, qz, thr0, top);
 
     // the group's sorted lists -> one, held by every lane of the group
     dpp_merge<KC, kDppXor1>(top);
     dpp_merge<KC, kDppXor2>(top);
+    if constexpr (kQuadLanes == 8) dpp_merge<KC, kDppHalfMirror>(top);  // the other quad of the group
 
     const unsigned kth_bits = top.kth_bits(K);  // the K-th best, not the list's last slot
     const bool full = kth_bits < 0x7f800000u;
@@ -730,7 +687,7 @@ static void launch_grid_passes(const KnnArgs& a, const GridWs& ws, bool quad) {
   if constexpr (KC <= 32) if (quad) {
     int64_t wx = a.P1 / (32 * kQuadQueries);  // a few % of a cloud arrive here
     wx = wx < 8 ? 8 : wx > 4096 ? 4096 : wx;
-    hipLaunchKernelGGL((knn_grid_quad_kernel<D, KC, NORM>), dim3((unsigned)wx, (unsigned)a.N), dim3(kGridWave), 0,
+    hipLaunchKernelGGL((knn_grid_quad_kernel<D, KC, NORM, RB>), dim3((unsigned)wx, (unsigned)a.N), dim3(kGridWave), 0,
                        a.stream, a.p1, (const GridCloud*)ws.cloud, (const float*)ws.edges, (const int*)ws.cell_start,
                        (const float4*)ws.sorted, (const int*)ws.fb_count, (const int*)ws.fb_list,
                        (const unsigned*)ws.fb_kth, ws.fb3_count, ws.fb3_list, ws.box_count, ws.box_list, ws.cell_cap, a.P1,
