@@ -228,3 +228,16 @@ def test_pointclouds_container_against_reference_fixture():
     assert sub.num_points_per_cloud().tolist() == [100, 800] and sub.get_features_list("colors")[0].shape == (100, 3)
     assert st.subsample(pc, 5000) is pc
     assert st.all_close(pc, pc.clone()) and not st.all_close(pc, sc)
+
+
+def test_graph_capture_has_no_cpu_path():
+    """graphs.capture is a GPU tool: CPU tensors raise before anything is captured (no silent eager fallback)."""
+    import pytest
+    import torch
+
+    from pytorch3d_pointops_amd import graphs
+
+    with pytest.raises(RuntimeError, match="GPU tensors"):
+        graphs.capture(lambda p: p * 2, (torch.zeros(2, 8, 3),))
+    with pytest.raises(RuntimeError, match="GPU tensors"):
+        graphs.capture(lambda: None, ())
