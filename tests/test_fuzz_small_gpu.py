@@ -7,6 +7,12 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# POINTOPS_FUZZ_SOAK=<int> shifts every seed: `for s in 1000 2000 ...; do POINTOPS_FUZZ_SOAK=$s pytest tests/test_fuzz_small_gpu.py; done`
+# draws fresh cases (the committed run, offset 0, is what the suite pins).
+import os  # noqa: E402
+
+_SOAK = int(os.environ.get("POINTOPS_FUZZ_SOAK", "0"))
+
 
 def _G(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -34,7 +40,7 @@ def _bits(a):
 def test_fuzz_knn_small(dev, oracle, monkeypatch, seed):
     from pytorch3d_pointops_amd import _C
 
-    rng = np.random.default_rng(100 + seed)
+    rng = np.random.default_rng(100 + seed + _SOAK)
     for it in range(25):
         lattice = rng.random() < 0.3
         N, P1, P2 = int(rng.integers(1, 6)), int(rng.integers(1, 700)), int(rng.integers(1, 3000))
@@ -56,7 +62,7 @@ def test_fuzz_knn_small(dev, oracle, monkeypatch, seed):
 def test_fuzz_ball_small(dev, oracle, monkeypatch, seed):
     from pytorch3d_pointops_amd import _C
 
-    rng = np.random.default_rng(200 + seed)
+    rng = np.random.default_rng(200 + seed + _SOAK)
     for it in range(25):
         lattice = rng.random() < 0.3
         N, P1, P2 = int(rng.integers(1, 6)), int(rng.integers(1, 700)), int(rng.integers(1, 3000))
@@ -77,7 +83,7 @@ def test_fuzz_ball_small(dev, oracle, monkeypatch, seed):
 def test_fuzz_fps_small(dev, oracle, monkeypatch, seed):
     from pytorch3d_pointops_amd import _C
 
-    rng = np.random.default_rng(300 + seed)
+    rng = np.random.default_rng(300 + seed + _SOAK)
     for it in range(25):
         lattice = rng.random() < 0.3
         N, P, D = int(rng.integers(1, 6)), int(rng.integers(1, 5000)), int(rng.choice([2, 3]))
@@ -99,7 +105,7 @@ def test_fuzz_knn_grid(dev, oracle, monkeypatch, seed):
     size class, lattices (ties), self-queries; the quad pass forced on and off."""
     from pytorch3d_pointops_amd import _C
 
-    rng = np.random.default_rng(400 + seed)
+    rng = np.random.default_rng(400 + seed + _SOAK)
     for it in range(10):
         lattice = rng.random() < 0.3
         N, P1, P2 = int(rng.integers(1, 5)), int(rng.integers(1, 3000)), int(rng.integers(1, 6000))
@@ -126,7 +132,7 @@ def test_fuzz_ball_grid_and_fps_clusters(dev, oracle, monkeypatch, seed):
     """Ball query through the cell grid (forced) and FPS through multi-workgroup clusters on random ragged batches."""
     from pytorch3d_pointops_amd import _C
 
-    rng = np.random.default_rng(500 + seed)
+    rng = np.random.default_rng(500 + seed + _SOAK)
     for it in range(8):
         lattice = rng.random() < 0.25
         N, P1, P2 = int(rng.integers(1, 5)), int(rng.integers(1, 3000)), int(rng.integers(1, 6000))
@@ -161,7 +167,7 @@ def test_fuzz_backward_and_gather(dev, oracle, monkeypatch, seed):
     from oracle import oracle as O
     from pytorch3d_pointops_amd import _C
 
-    rng = np.random.default_rng(600 + seed)
+    rng = np.random.default_rng(600 + seed + _SOAK)
     for it in range(12):
         N, P1, P2 = int(rng.integers(1, 5)), int(rng.integers(1, 900)), int(rng.integers(1, 2500))
         D, K, norm = int(rng.integers(1, 7)), int(rng.choice([1, 3, 8, 16, 33])), int(rng.integers(1, 3))
@@ -185,7 +191,8 @@ def test_fuzz_backward_and_gather(dev, oracle, monkeypatch, seed):
             if det:
                 assert np.array_equal(_bits(g2.cpu().numpy()), _bits(w2)), what
             else:
-                assert np.allclose(g2.cpu().numpy(), w2, rtol=1e-5, atol=1e-5), what
+                # (atomically accumulated: the order differs from the oracle's; the deterministic form above pins the values)
+                assert np.allclose(g2.cpu().numpy(), w2, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(w2).max()))), what
         monkeypatch.delenv("POINTOPS_DEBUG")
         U = int(rng.integers(1, 9))
         x = _cloud(rng, (N, P2, U), False)
@@ -203,7 +210,7 @@ def test_fuzz_wide_families_and_packing(dev, oracle, seed):
     and sample_pdf on random ragged inputs, against the oracle."""
     from pytorch3d_pointops_amd import _C
 
-    rng = np.random.default_rng(700 + seed)
+    rng = np.random.default_rng(700 + seed + _SOAK)
     for it in range(10):
         N, P1, P2 = int(rng.integers(1, 4)), int(rng.integers(1, 400)), int(rng.integers(1, 1500))
         D, K = int(rng.choice([1, 3, 4, 9, 16, 33, 70])), int(rng.choice([1, 5, 32, 33, 64, 65, 100, 130]))
@@ -252,7 +259,7 @@ def test_fuzz_chamfer_native_vs_composed(dev, monkeypatch, seed):
     random ragged batches, reductions, norms and optional normals: losses and all gradients."""
     import pytorch3d_pointops_amd.functions.chamfer as ch
 
-    rng = np.random.default_rng(800 + seed)
+    rng = np.random.default_rng(800 + seed + _SOAK)
     for it in range(8):
         N, P1, P2 = int(rng.integers(1, 6)), int(rng.integers(2, 900)), int(rng.integers(2, 1200))
         l1 = np.maximum(_lengths(rng, N, P1), 1)
@@ -285,8 +292,10 @@ def test_fuzz_chamfer_native_vs_composed(dev, monkeypatch, seed):
             assert u.shape == v.shape, what
             assert np.allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-5, atol=1e-6), what
         for k in base:
-            # (normals of length ~0 give cosine gradients of size ~1/|n| with cancellation inside: the absolute term scales
-            # with the largest gradient of the tensor)
+            # (normals of length ~0 give cosine gradients of size ~1/|n| with cancellation inside, and a target normal
+            # sums such terms from every point it is nearest to, in a different order on the two paths: the absolute
+            # term scales with the largest gradient of the tensor)
             u, v = a[1][k].cpu().numpy(), b[1][k].cpu().numpy()
-            tol = 2e-5 * np.abs(v) + 2e-6 * max(1.0, float(np.abs(v).max()))
+            # (and with a one-point cloud on one side that point's gradient is a sum of ~1000 atomically added terms)
+            tol = 1e-4 * np.abs(v) + 1e-5 * max(1.0, float(np.abs(v).max()))
             assert (np.abs(u - v) <= tol).all(), (k, float((np.abs(u - v) - tol).max()), what)
