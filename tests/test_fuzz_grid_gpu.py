@@ -85,3 +85,39 @@ def test_fuzz_grid_family_vs_brute_force(dev, monkeypatch, seed):
         if si is not None:
             wi, wd = _C.knn_points_idx(tb, tb.clone(), t2, t2.clone(), norm, K, 0)
             assert torch.equal(si, wi) and torch.equal(sd.view(torch.int32), wd.view(torch.int32)), dict(what, self_query=True)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_ball_query_grid_vs_scan(dev, monkeypatch, seed):
+    """ball_query: the cell-grid path and the coarse-cell query order (forced wherever the shape allows, and by the
+    automatic rule) against the storage-order scan without workspace (`ball_grid=0`, pinned by the oracle and the
+    reference's goldens elsewhere), bit for bit, radii from a fraction of the point spacing to the whole cloud."""
+    from pytorch3d_pointops_amd import _C
+
+    rng = np.random.default_rng(950 + seed + _SOAK)
+    kinds = ["uniform", "clusters", "lattice", "slab", "u4"]
+    for it in range(8):
+        d = int(rng.choice([1, 2, 3, 3, 3]))
+        n = int(rng.integers(1, 5))
+        p1, p2 = int(rng.integers(300, 30000)), int(rng.integers(300, 50000))
+        K = int(rng.choice([1, 4, 8, 16, 32, 33, 64]))
+        radius = float(10.0 ** rng.uniform(-3, 0.3))
+        k1, k2 = kinds[int(rng.integers(0, 5))], kinds[int(rng.integers(0, 5))]
+        a, b = _draw(rng, n, p1, d, k1), _draw(rng, n, p2, d, k2)
+        l1 = rng.integers(1, p1 + 1, n).astype(np.int64)
+        l2 = rng.integers(1, p2 + 1, n).astype(np.int64)
+        l1[int(rng.integers(0, n))] = p1
+        l2[int(rng.integers(0, n))] = p2
+        ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+        t1, t2 = torch.from_numpy(l1).to(dev), torch.from_numpy(l2).to(dev)
+        monkeypatch.setenv("POINTOPS_DEBUG", "ball_grid=0")
+        want_i, want_d = _C.ball_query(ta, tb, t1, t2, K, radius)
+        what = dict(seed=seed, it=it, d=d, n=n, p1=p1, p2=p2, K=K, radius=radius, k1=k1, k2=k2, l1=l1.tolist(), l2=l2.tolist())
+        for knob in ("ball_grid=1", "ball_grid=1,ball_order=0", "ball_grid=1,ball_stage=0", ""):
+            if knob:
+                monkeypatch.setenv("POINTOPS_DEBUG", knob)
+            else:
+                monkeypatch.delenv("POINTOPS_DEBUG", raising=False)
+            got_i, got_d = _C.ball_query(ta, tb, t1, t2, K, radius)
+            assert torch.equal(got_i, want_i), dict(what, knob=knob)
+            assert torch.equal(got_d.view(torch.int32), want_d.view(torch.int32)), dict(what, knob=knob)
